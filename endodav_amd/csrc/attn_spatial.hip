@@ -1,0 +1,171 @@
+// Encoder self-attention core, fp32, flash-style (no N x N score matrix in HBM).
+// Restates models/backbones/layers/attention.py:60-66:  softmax((q * d^-0.5) kᵀ) v, d = 64.
+//
+// Layout: qkv [F*N, 3*heads*64] exactly as the qkv linear writes it (columns [3][heads][64]);
+// out [F*N, heads*64] (= attn.transpose(1,2).reshape(B,N,C) of the reference).
+//
+// Workgroup = 4 waves = 128 queries of one (frame, head); each wave owns 32 queries and sweeps
+// the keys in tiles of 64 staged through LDS (shared by the 4 waves).  All products run on
+// v_mfma_f32_32x32x2_f32 in the TRANSPOSED orientation, so the query index sits on the lane:
+//     Sᵀ[key, q]  = K · Qᵀ      A = K tile (LDS, b128 reads with the permuted-k trick of gemm.hip)
+//                               B = Qᵀ (registers for the whole kernel, pre-scaled by d^-0.5 * log2 e)
+//     Oᵀ[d, q]   += Vᵀ · Pᵀ     A = Vᵀ (LDS, one b32 per MFMA),  B = Pᵀ = the Sᵀ accumulator registers
+// With queries on lanes the softmax row reductions are 31 in-lane max/adds plus ONE cross-half
+// shuffle, the running max / sum / rescale factor are per-lane scalars, and the probabilities
+// feed the second product straight from the accumulator registers: the accumulator's row map
+// key = (r&3) + 8*(r>>2) + 4*(lane>>5) assigns register r of lane-half h exactly the k-slot h
+// of MFMA step r, so no data moves between the two products.
+#include "ops.hpp"
+
+namespace edv {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int HD = 64;       // head dim
+constexpr int KT = 64;       // keys per LDS tile
+constexpr int KS = HD + 4;   // padded K row stride: 68r mod 64 = 4r -> conflict-free b128
+constexpr int QB = 128;      // queries per workgroup
+
+__global__ __launch_bounds__(256) void attn_spatial_kernel(const float *__restrict__ qkv, float *__restrict__ out, int N, int heads) {
+    __shared__ __attribute__((aligned(16))) float smem[KT * KS + KT * HD];
+    float *sK = smem;
+    float *sV = smem + KT * KS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int head = blockIdx.y, frame = blockIdx.z;
+    const int D = heads * HD, D3 = 3 * D;
+    const float *base = qkv + (long long)frame * N * D3 + head * HD;
+
+    const int qi = blockIdx.x * QB + wave * 32 + l31;
+    const int qrow = qi < N ? qi : N - 1;
+
+    // Q fragment in permuted-k order: element e of qf[qq] is d = 8*qq + 4*lh + e
+    const float qscale = 0.125f * 1.44269504088896340736f;  // d^-0.5 (exact) * log2(e)
+    f32x4 qf[8];
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq) {
+        f32x4 v = *reinterpret_cast<const f32x4 *>(base + (long long)qrow * D3 + 8 * qq + 4 * lh);
+        qf[qq] = v * qscale;
+    }
+
+    f32x16 o0, o1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    // staging slots: 16 float4 per 64-float row; thread -> (row sr + 16*i, chunk sc)
+    const int sc = tid & 15, sr = tid >> 4;
+    f32x4 rk[4], rv[4];
+    auto load_tile = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int kr = k0 + sr + 16 * i;
+            kr = kr < N ? kr : N - 1;  // clamped rows are masked below
+            const float *p = base + (long long)kr * D3 + sc * 4;
+            rk[i] = *reinterpret_cast<const f32x4 *>(p + D);
+            rv[i] = *reinterpret_cast<const f32x4 *>(p + 2 * D);
+        }
+    };
+
+    const int ntiles = (N + KT - 1) / KT;
+    load_tile(0);
+    for (int t = 0; t < ntiles; ++t) {
+        const int k0 = t * KT;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4 *>(&sK[(sr + 16 * i) * KS + sc * 4]) = rk[i];
+            *reinterpret_cast<f32x4 *>(&sV[(sr + 16 * i) * HD + sc * 4]) = rv[i];
+        }
+        __syncthreads();
+        if (t + 1 < ntiles) load_tile(k0 + KT);
+
+        // ---- Sᵀ = K Qᵀ : two 32-key sub-tiles
+        f32x16 s0, s1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) {
+            const f32x4 ka = *reinterpret_cast<const f32x4 *>(&sK[l31 * KS + 8 * qq + 4 * lh]);
+            const f32x4 kb = *reinterpret_cast<const f32x4 *>(&sK[(32 + l31) * KS + 8 * qq + 4 * lh]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[e], qf[qq][e], s0, 0, 0, 0);
+                s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[e], qf[qq][e], s1, 0, 0, 0);
+            }
+        }
+        if (k0 + KT > N) {  // last tile: keys past the sequence end
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (key >= N) s0[r] = -INFINITY;
+                if (key + 32 >= N) s1[r] = -INFINITY;
+            }
+        }
+
+        // ---- online softmax in base 2; this lane holds 32 of its query's 64 scores, lane^32 the rest
+        float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0
+        m_run = m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
+            s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
+            psum += s0[r] + s1[r];
+        }
+        l_run = l_run * alpha + psum;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            o0[r] *= alpha;
+            o1[r] *= alpha;
+        }
+
+        // ---- Oᵀ += Vᵀ Pᵀ : step r of sub-tile s contracts keys {key(r,0), key(r,1)}
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float va0 = sV[key * HD + l31], va1 = sV[key * HD + 32 + l31];
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va0, s0[r], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va1, s0[r], o1, 0, 0, 0);
+            const float vb0 = sV[(32 + key) * HD + l31], vb1 = sV[(32 + key) * HD + 32 + l31];
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vb0, s1[r], o0, 0, 0, 0);
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vb1, s1[r], o1, 0, 0, 0);
+        }
+    }
+
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.0f / l_tot;
+    if (qi < N) {
+        float *orow = out + ((long long)frame * N + qi) * D + head * HD;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 are d = 8g + 4*lh + {0..3}
+            f32x4 a = {o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
+            f32x4 b = {o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
+            *reinterpret_cast<f32x4 *>(orow + 8 * g + 4 * lh) = a;
+            *reinterpret_cast<f32x4 *>(orow + 32 + 8 * g + 4 * lh) = b;
+        }
+    }
+}
+
+}  // namespace
+
+int attn_spatial(const float *qkv, float *out, int F, int N, int heads, hipStream_t st) {
+    EDV_CHECK(qkv && out, "null operand");
+    EDV_CHECK(F > 0 && N > 0 && heads > 0, "empty problem");
+    EDV_CHECK(F <= 65535 && heads <= 65535, "grid limits");
+    EDV_CHECK(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 16 == 0), "16-byte alignment");
+    dim3 grid((N + QB - 1) / QB, heads, F), block(256);
+    hipLaunchKernelGGL(attn_spatial_kernel, grid, block, 0, st, qkv, out, N, heads);
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
+}  // namespace edv

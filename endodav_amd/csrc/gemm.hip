@@ -1,0 +1,266 @@
+// fp32 GEMM family on v_mfma_f32_32x32x2_f32 (exact f32, 64 FLOP/clk/SIMD; MI355X peak 157.3 TF).
+//
+// Covers every dense contraction of EndoDAV's forward outside the two attention cores:
+//   F.linear            layers/attention.py:58,67  layers/mlp.py:34-37  motion_module.py:113,120
+//   1x1 / 3x3 Conv2d    dpt.py:60-68,86-90,117-124  util/blocks.py:20-32,52-58,117
+//   ConvTranspose2d k=s dpt.py:71-82 (as GEMM + pixel-shuffle store)
+//   patch-embed conv    patch_embed.py:65,75 (after im2col by the patchify kernel)
+//
+// Tiling: workgroup = 256 threads = 4 waves, tile BM x BN x 32.  A and W tiles are staged
+// global -> VGPR -> LDS (loads of tile k+1 are issued before the MFMAs of tile k, written
+// after the barrier: the T14 split of the CDNA guide).  LDS rows are padded to 36 floats, which
+// makes the ds_read_b128 fragment reads conflict-free (36r mod 64 is a bijection on r mod 16).
+//
+// K-order trick: the f32 MFMA takes ONE k per lane-half per instruction (lane l supplies
+// A[l&31][l>>5]).  Instead of two ds_read_b32 per instruction, lane-half h reads the float4
+// k = 8q+4h .. 8q+4h+3 of its row once and feeds element e to MFMA (q,e); A and W use the same
+// permutation of k, so the sum over k is unchanged, and LDS traffic drops to one b128 per 4 MFMAs.
+#include "ops.hpp"
+
+namespace edv {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LS = BK + 4;  // padded LDS row stride (floats)
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == ACT_GELU) return gelu_erf(v);
+    if (act == ACT_RELU) return fmaxf(v, 0.0f);
+    return v;
+}
+
+template <int BM, int BN, int WGM, int WGN, int LOADER, int STORE>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc g) {
+    constexpr int WTM = BM / WGM, WTN = BN / WGN;
+    constexpr int FM = WTM / 32, FN = WTN / 32;
+    constexpr int RA = BM / 32, RB = BN / 32;  // float4 loads per thread per tile
+    static_assert(WGM * WGN == 4 && FM >= 1 && FN >= 1, "4 waves");
+
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LS];
+    float *sA = smem;
+    float *sB = smem + BM * LS;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    // XCD-aware, bijective block remap: blocks b and b+8 share an XCD (and its L2); give each XCD a
+    // contiguous run of tiles, n fastest, so the column tiles of one A row-panel hit the same L2.
+    const int tiles_n = (g.N + BN - 1) / BN;
+    int bid = blockIdx.x;
+    {
+        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, x = bid & 7, loc = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+    }
+    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
+    const long long m0 = (long long)tm * BM;
+    const int n0 = tn * BN;
+
+    // ---- per-thread load slots: chunk c (4 consecutive k), rows r0 + 32*i ----
+    const int c = tid & 7, r0 = tid >> 3;
+    const float *a_ptr[RA];  // dense: row base; conv: frame base
+    int a_iy[RA], a_ix[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        const long long m = m0 + r0 + 32 * i;
+        if (m < g.M) {
+            if (LOADER == LOAD_DENSE) {
+                a_ptr[i] = g.A + g.a_map(m) * g.lda;
+                a_iy[i] = a_ix[i] = 0;
+            } else {
+                const int opix = g.cOH * g.cOW;
+                const long long f = m / opix;
+                const int p = (int)(m - f * opix);
+                const int oy = p / g.cOW, ox = p - oy * g.cOW;
+                a_ptr[i] = g.A + f * (long long)g.cH * g.cW * g.cC;
+                a_iy[i] = oy * g.cS - 1;
+                a_ix[i] = ox * g.cS - 1;
+            }
+        } else {
+            a_ptr[i] = nullptr;
+            a_iy[i] = a_ix[i] = 0;
+        }
+    }
+    const float *b_ptr[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int n = n0 + r0 + 32 * i;
+        b_ptr[i] = (n < g.N) ? g.W + (long long)n * g.ldw : nullptr;
+    }
+
+    f32x4 ra[RA], rb[RB];
+    auto load_tile = [&](int kt) {
+        const int k = kt * BK + c * 4;
+        const bool kin = k < g.K;  // K % 4 == 0, so a chunk is wholly in or out
+        if (LOADER == LOAD_DENSE) {
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (kin && a_ptr[i]) v = *reinterpret_cast<const f32x4 *>(a_ptr[i] + k);
+                ra[i] = v;
+            }
+        } else {
+            const int tap = k / g.cC, ci = k - tap * g.cC;  // Cin % 4 == 0: chunk never straddles a tap
+            const int dy = tap / 3, dx = tap - dy * 3;
+#pragma unroll
+            for (int i = 0; i < RA; ++i) {
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                const int iy = a_iy[i] + dy, ix = a_ix[i] + dx;
+                if (kin && a_ptr[i] && iy >= 0 && iy < g.cH && ix >= 0 && ix < g.cW) {
+                    v = *reinterpret_cast<const f32x4 *>(a_ptr[i] + ((long long)iy * g.cW + ix) * g.cC + ci);
+                    if (g.pre_relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                }
+                ra[i] = v;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (kin && b_ptr[i]) v = *reinterpret_cast<const f32x4 *>(b_ptr[i] + k);
+            rb[i] = v;
+        }
+    };
+
+    f32x16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nkt = (g.K + BK - 1) / BK;
+    load_tile(0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();  // previous tile's fragment reads are done
+#pragma unroll
+        for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4 *>(&sA[(r0 + 32 * i) * LS + c * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4 *>(&sB[(r0 + 32 * i) * LS + c * 4]) = rb[i];
+        __syncthreads();
+        if (kt + 1 < nkt) load_tile(kt + 1);  // in flight under the MFMAs below
+
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            f32x4 fa[FM], fb[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(&sA[(wm * WTM + i * 32 + l31) * LS + 8 * q + 4 * lh]);
+#pragma unroll
+            for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(&sB[(wn * WTN + j * 32 + l31) * LS + 8 * q + 4 * lh]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + l31;
+        if (n >= g.N) continue;
+        const float bias = g.bias ? g.bias[n] : 0.f;
+        const float gam = g.gamma ? g.gamma[n] : 1.f;
+        int ps_sub = 0, ps_co = 0, ps_dy = 0, ps_dx = 0;
+        if (STORE == STORE_SHUFFLE) {
+            ps_sub = n / g.ps_C;
+            ps_co = n - ps_sub * g.ps_C;
+            ps_dy = ps_sub / g.ps_s;
+            ps_dx = ps_sub - ps_dy * g.ps_s;
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const long long m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= g.M) continue;
+                float v = apply_act(acc[i][j][r] + bias, g.act) * gam;
+                if (STORE == STORE_ROWS) {
+                    const long long crow = g.c_map(m);
+                    if (g.R1) v += g.R1[g.r1_map(m) * g.ldr1 + n];
+                    if (g.R2) v += g.R2[crow * g.ldr2 + n];
+                    g.C[crow * g.ldc + n] = v;
+                } else {
+                    const int gp = g.ps_h * g.ps_w;
+                    const long long f = m / gp;
+                    const int p = (int)(m - f * gp);
+                    const int y = p / g.ps_w, x = p - y * g.ps_w;
+                    const long long orow = (f * g.ps_h * g.ps_s + (long long)y * g.ps_s + ps_dy) * (g.ps_w * g.ps_s) + x * g.ps_s + ps_dx;
+                    g.C[orow * g.ps_C + ps_co] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WGM, int WGN>
+int launch_tile(const GemmDesc &d, hipStream_t st) {
+    const long long tiles = ((d.M + BM - 1) / BM) * (long long)((d.N + BN - 1) / BN);
+    EDV_CHECK(tiles > 0 && tiles < (1ll << 31), "bad grid");
+    dim3 grid((unsigned)tiles), block(256);
+    if (d.loader == LOAD_DENSE && d.store == STORE_ROWS)
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, LOAD_DENSE, STORE_ROWS>), grid, block, 0, st, d);
+    else if (d.loader == LOAD_CONV3 && d.store == STORE_ROWS)
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, LOAD_CONV3, STORE_ROWS>), grid, block, 0, st, d);
+    else if (d.loader == LOAD_DENSE && d.store == STORE_SHUFFLE)
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, LOAD_DENSE, STORE_SHUFFLE>), grid, block, 0, st, d);
+    else
+        EDV_CHECK(false, "unsupported loader/store combination");
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
+// 0: 128x128, 1: 128x64, 2: 128x32, 3: 64x64
+int pick_tile(const GemmDesc &d) {
+    auto blocks = [&](int bm, int bn) { return ((d.M + bm - 1) / bm) * (long long)((d.N + bn - 1) / bn); };
+    if (d.N <= 32) return 2;
+    // 128-wide tiles only when they add no column padding over 64-wide ones and still give the
+    // 256 CUs ~3 workgroups each; otherwise trade tile size for occupancy.
+    const bool n128_free = ((d.N + 127) / 128) * 128 == ((d.N + 63) / 64) * 64;
+    if (n128_free && blocks(128, 128) >= 768) return 0;
+    if (blocks(128, 64) >= 512) return 1;
+    return 3;
+}
+
+}  // namespace
+
+int gemm(const GemmDesc &d, hipStream_t st) {
+    EDV_CHECK(d.A && d.W && d.C, "null operand");
+    EDV_CHECK(d.M > 0 && d.N > 0 && d.K > 0, "empty problem");
+    EDV_CHECK(d.K % 4 == 0, "K must be a multiple of 4");
+    EDV_CHECK(d.ldw % 4 == 0 && d.ldw >= d.K, "ldw");
+    if (d.loader == LOAD_DENSE) {
+        EDV_CHECK(d.lda % 4 == 0 && d.lda >= d.K, "lda");
+    } else {
+        EDV_CHECK(d.cC % 4 == 0 && d.K == 9 * d.cC, "conv3x3: Cin % 4, K = 9*Cin");
+        EDV_CHECK(d.cS == 1 || d.cS == 2, "conv stride");
+        EDV_CHECK(d.cOH == (d.cH + 2 - 3) / d.cS + 1 && d.cOW == (d.cW + 2 - 3) / d.cS + 1, "conv output size");
+    }
+    if (d.store == STORE_SHUFFLE) {
+        EDV_CHECK(d.ps_s > 0 && d.N == d.ps_s * d.ps_s * d.ps_C, "pixel-shuffle N");
+        EDV_CHECK(d.R1 == nullptr && d.R2 == nullptr, "pixel-shuffle store takes no residual");
+    }
+    EDV_CHECK(((uintptr_t)d.A % 16 == 0) && ((uintptr_t)d.W % 16 == 0), "A/W must be 16-byte aligned");
+    switch (pick_tile(d)) {
+        case 0: return launch_tile<128, 128, 2, 2>(d, st);
+        case 1: return launch_tile<128, 64, 2, 2>(d, st);
+        case 2: return launch_tile<128, 32, 4, 1>(d, st);
+        default: return launch_tile<64, 64, 2, 2>(d, st);
+    }
+}
+
+const char *gemm_kernel_name(const GemmDesc &d) {
+    static const char *names[] = {"gemm_128x128", "gemm_128x64", "gemm_128x32", "gemm_64x64"};
+    return names[pick_tile(d)];
+}
+
+}  // namespace edv

@@ -1,0 +1,90 @@
+// Host-side launch functions of the HIP kernels (one per op family).  All pointers are device
+// pointers; every function enqueues on `st` and returns 0 / non-zero (text via edv::get_error()).
+#pragma once
+#include "common.hpp"
+
+namespace edv {
+
+// ------------------------------------------------------------------------------------------
+// GEMM family (gemm.hip):  C = epilogue(Aop · Wᵀ),  W [N,K] row-major (torch Linear layout).
+//   epilogue:  v = acc + bias[n];  v = act(v);  v *= gamma[n];  v += R1[r1_map(m), n];  v += R2[c_row, n]
+// A operand:  LOAD_DENSE  A[a_map(m), k]
+//             LOAD_CONV3  implicit im2col of a channels-last image x[F,H,W,Cin], k = (ky*3+kx)*Cin+ci,
+//                         zero padding 1, stride cs, optional ReLU on the loaded value
+// C store:    STORE_ROWS  C[c_map(m), n]
+//             STORE_SHUFFLE  ConvTranspose2d with kernel == stride == s as a GEMM: m = (f,y,x) on a
+//                         [ps_h, ps_w] grid, n = (dy*s+dx)*ps_C + co -> out[f, y*s+dy, x*s+dx, co]
+// ------------------------------------------------------------------------------------------
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_RELU = 2, ACT_SIGMOID = 3, ACT_SIGMOID_NEG = 4 };
+enum { LOAD_DENSE = 0, LOAD_CONV3 = 1 };
+enum { STORE_ROWS = 0, STORE_SHUFFLE = 1 };
+
+struct GemmDesc {
+    const float *A = nullptr;
+    int lda = 0;
+    RowMap a_map{0, 0, 0};
+    const float *W = nullptr;
+    int ldw = 0;
+    float *C = nullptr;
+    int ldc = 0;
+    RowMap c_map{0, 0, 0};
+    long long M = 0;
+    int N = 0, K = 0;
+    const float *bias = nullptr;
+    int act = ACT_NONE;
+    const float *gamma = nullptr;
+    const float *R1 = nullptr;
+    int ldr1 = 0;
+    RowMap r1_map{0, 0, 0};
+    const float *R2 = nullptr;
+    int ldr2 = 0;
+    int loader = LOAD_DENSE;
+    int cH = 0, cW = 0, cC = 0, cOH = 0, cOW = 0, cS = 1, pre_relu = 0;
+    int store = STORE_ROWS;
+    int ps_s = 0, ps_C = 0, ps_h = 0, ps_w = 0;
+};
+int gemm(const GemmDesc &d, hipStream_t st);
+// flops of the last-launched gemm tile choice, for the bench's roofline bookkeeping
+const char *gemm_kernel_name(const GemmDesc &d);
+
+// ------------------------------------------------------------------------------------------
+// attention (attn_spatial.hip, temporal.hip)
+// ------------------------------------------------------------------------------------------
+int attn_spatial(const float *qkv, float *out, int F, int N, int heads, hipStream_t st);
+int attn_temporal(const float *qkv, float *out, int B, int T, int P, int C, int heads, hipStream_t st);
+int geglu(const float *x, float *y, long long M, int inner, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------
+// norms (norms.hip)
+// ------------------------------------------------------------------------------------------
+// y[out_map(m)] = LN(x[in_map(m)]) * w + b (+ pe[(m / rows_per_frame) % T])
+int layernorm(const float *x, RowMap in_map, const float *w, const float *b, float *y, RowMap out_map, long long rows, int dim,
+              float eps, const float *pe, int rows_per_frame, int T, hipStream_t st);
+int groupnorm(const float *x, const float *w, const float *b, float *y, float *stats, int F, int P, int C, int groups, float eps,
+              hipStream_t st);
+
+// ------------------------------------------------------------------------------------------
+// resampling / elementwise (resample.hip)
+// ------------------------------------------------------------------------------------------
+int patchify(const float *x, float *cols, int F, int H, int W, int ih, int iw, hipStream_t st);
+int bilinear(const float *x, float *y, int F, int H, int W, int C, int OH, int OW, int act, hipStream_t st);
+int dot_channels(const float *x, const float *w, const float *b, float *y, long long M, int C, int act, hipStream_t st);
+int cls_rows(const float *cls, const float *pos, float *tokens, int F, int ntok, int D, hipStream_t st);
+int sigmoid_inplace(float *x, long long n, hipStream_t st);
+// pos-embed bicubic resample (vision_transformer.py:186-217): grid [S,S,D] -> [oh,ow,D]
+int bicubic_pos(const float *grid, float *out, int S, int D, int oh, int ow, float scale_h, float scale_w, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------
+// weight packing (prep.hip)
+// ------------------------------------------------------------------------------------------
+int pack_conv3x3(const float *w, float *out, int Cout, int Cin, hipStream_t st);            // [Co,Ci,3,3] -> [Co][3][3][Ci]
+int pack_convT(const float *w, float *wout, const float *b, float *bout, int Cin, int Cout, int s, hipStream_t st);  // [Ci,Co,s,s] -> [(dy,dx,co)][ci]
+int copy_f32(const float *src, float *dst, long long n, hipStream_t st);
+// W_eff = W + scale * (B∘V)(A∘U)   (U,V may be null);   ssb: W_eff = a ∘ W ∘ b
+int fold_lora(const float *W, const float *A, const float *B, const float *U, const float *V, float scale, float *out, int nout, int nin,
+              int r, hipStream_t st);
+int fold_ssb(const float *W, const float *a, const float *b, float *out, int nout, int nin, hipStream_t st);
+// W_eff += Utop diag(idx) Vtop  (DashLinear after warm-up)
+int fold_dash(const float *Utop, const float *idx, const float *Vtop, float *inout, int nout, int nin, int r, hipStream_t st);
+
+}  // namespace edv

@@ -1,0 +1,150 @@
+/*
+ * endodav_hip.h — C ABI of libendodav_hip.so: the MI355X (gfx950) implementation of
+ * EndoDAV's per-clip forward.
+ *
+ * The reference has no FFI / plugin registry for this path: its boundary is the Python
+ * class surface models/endodav/__init__.py:1-2.  This header is the
+ * boundary the build's own host module (endodav_amd/endodav.py, a mirror of
+ * models/endodav/endodav.py:53-160) binds through ctypes; INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.  Rules of the ABI:
+ *
+ *   - plain C types only: device pointers, sizes, an opaque context; no torch types;
+ *   - every pointer named *_dev is a device pointer on the CURRENT HIP device;
+ *   - every call is stream-ordered on `stream` (a hipStream_t passed as void*; NULL = the
+ *     legacy default stream) and performs no host/device synchronisation, except
+ *     edv_create/edv_destroy and the first edv_forward at a new clip geometry, which
+ *     allocate the activation workspace (hipMalloc);
+ *   - return value 0 = ok, non-zero = error, text in edv_last_error(); nothing throws;
+ *   - one context per device and per host thread (nn.DataParallel replicas each own one);
+ *     the library keeps no global mutable state besides the thread-local error string.
+ *
+ * Data layout: activations are fp32, tokens-major [frames*tokens, D] in the
+ * encoder and channels-last [frames, h, w, C] in the DPT head; the clip comes in as the
+ * reference's [B, T, 3, H, W] and the disparities go out as [B*T, 1, h_s, w_s].
+ */
+#ifndef ENDODAV_HIP_H
+#define ENDODAV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EDV_ABI_VERSION 1
+
+enum edv_lora_type { EDV_LORA_NONE = 0, EDV_LORA_LORA = 1, EDV_LORA_DVLORA = 2, EDV_LORA_SSB = 3, EDV_LORA_DASH = 4 };
+
+/* Mirrors the constructor of the reference model, models/endodav/endodav.py:53-73, after the
+ * encoder name has been resolved to dimensions (vision_transformer.py:352-398). */
+typedef struct edv_config {
+    int32_t abi_version;        /* EDV_ABI_VERSION */
+    int32_t embed_dim;          /* 384 / 768 / 1024 */
+    int32_t depth;              /* 12 / 12 / 24 */
+    int32_t num_heads;          /* 6 / 12 / 16 (head dim must be 64) */
+    int32_t taps[4];            /* intermediate_layer_idx, endodav.py:76-79 */
+    int32_t features;           /* DPT `features` */
+    int32_t out_channels[4];    /* DPT `out_channels` */
+    int32_t image_h, image_w;   /* `image_shape`; multiples of 14 (patch_embed.py:72-73) */
+    int32_t num_frames;         /* temporal_max_len; T <= num_frames (motion_module.py:197) */
+    int32_t pos_tokens;         /* rows of pretrained.pos_embed (1370, or 257 for vitl) */
+    int32_t lora_type;          /* enum edv_lora_type */
+    int32_t lora_rank;          /* r */
+    int32_t include_cls_token;  /* vision_transformer.py:229-230 */
+    int32_t conv_head;          /* 1 = four HeadDepth heads (default), 0 = disable_conv_head */
+    int32_t inv_sigmoid;        /* dpt_pyramid.py:104 */
+    int32_t out_sigmoid;        /* dpt_pyramid.py:97-101 */
+    int32_t temporal_lora;      /* endodav.py:119-137 */
+    int32_t dash_active;        /* DashLinear past warm-up: add U_top diag(idx) Vt_top */
+} edv_config;
+
+typedef struct edv_ctx edv_ctx;
+
+/* ---- life cycle ------------------------------------------------------------------------ */
+int edv_abi_version(void);
+const char *edv_last_error(void);
+int edv_create(const edv_config *cfg, edv_ctx **out);
+int edv_destroy(edv_ctx *ctx);
+
+/* Bind one entry of the model's state_dict (same key names as the reference)
+ * to device memory owned by the caller; zero-copy, the pointer must stay valid. */
+int edv_bind_param(edv_ctx *ctx, const char *name, const float *data_dev, const int64_t *shape, int32_t ndim);
+
+/* Re-derive the packed weights from the bound parameters: LoRA folded into fc1/fc2
+ * (mylora/layers.py:148-157,384-393,423-430), conv kernels repacked to [Cout][kh][kw][Cin],
+ * q/k/v concatenated, the position table resampled (vision_transformer.py:186-217).
+ * Call after every change of the bound tensors' contents. */
+int edv_prepare(edv_ctx *ctx, void *stream);
+
+/* endodav.forward (endodav.py:150-160).  x_dev: [B,T,3,H,W] fp32 in [0,1].  disp_dev[s] receives
+ * ("disp", s): VDA head [B*T,1,ih,iw], [..ih/2..], ...; conv head [B*T,1,2*ph*8*.. see
+ * edv_output_shape.  Requires T <= num_frames. */
+int edv_forward(edv_ctx *ctx, const float *x_dev, int32_t B, int32_t T, int32_t H, int32_t W,
+                float *const disp_dev[4], void *stream);
+/* h/w of ("disp", s) for this configuration. */
+int edv_output_shape(const edv_ctx *ctx, int32_t scale, int32_t *h, int32_t *w);
+/* Debug taps: copy of an internal stage of the last edv_forward, for the per-stage parity
+ * tests.  name in {"tokens","block0","tap0".."tap3","mm0","mm1","path4".."path1"}; head
+ * stages are channels-last [frames,h,w,C].  Returns element count through *n (dst may be NULL). */
+int edv_stage_copy(edv_ctx *ctx, const char *name, float *dst_dev, size_t *n, void *stream);
+/* Bytes of device memory the context currently holds (packed weights + workspace). */
+size_t edv_device_bytes(const edv_ctx *ctx);
+/* Seconds spent in the dominant kernels are measured by the caller with HIP events; this
+ * returns the number of kernel launches one edv_forward issued last time. */
+int edv_last_launch_count(const edv_ctx *ctx);
+
+/* ---- per-kernel entry points (unit tests, micro-benchmarks) --------------------------------
+ * All tensors fp32, row-major, device pointers. */
+
+/* y[m,:] = LN(x[m,:]) * w + b (+ pe[(m / rows_per_frame) % T, :] when pe_dev != NULL).
+ * vision_transformer.py:97 (eps 1e-6), motion_module.py:155,161 (eps 1e-5) + :197. */
+int edv_layernorm(const float *x_dev, const float *w_dev, const float *b_dev, float *y_dev, int64_t rows, int32_t dim,
+                  float eps, const float *pe_dev, int32_t rows_per_frame, int32_t T, void *stream);
+
+/* C[M,N] = epilogue(A[M,K] · W[N,K]ᵀ):  v = acc + bias[n]; v = act(v); v *= gamma[n]; v += R[m,n].
+ * act: 0 none, 1 exact-erf GELU, 2 ReLU.  bias/gamma/R may be NULL.  K % 4 == 0.
+ * F.linear / 1x1 conv with the epilogues of block.py:144-145, mlp.py:34-37. */
+int edv_gemm(const float *A_dev, const float *W_dev, float *C_dev, int64_t M, int32_t N, int32_t K, const float *bias_dev,
+             int32_t act, const float *gamma_dev, const float *R_dev, void *stream);
+
+/* 3x3 convolution, padding 1, stride 1 or 2, channels-last: x [F,H,W,Cin], w packed
+ * [Cout][3][3][Cin], y [F,OH,OW,Cout]; optional ReLU on the input (util/blocks.py:79-85),
+ * bias, ReLU on the output and up to two residual tensors shaped like y. */
+int edv_conv3x3(const float *x_dev, const float *wpacked_dev, const float *bias_dev, float *y_dev, int32_t F, int32_t H, int32_t W,
+                int32_t Cin, int32_t Cout, int32_t stride, int32_t pre_relu, int32_t post_relu, const float *R1_dev,
+                const float *R2_dev, void *stream);
+/* Repack a torch Conv2d weight [Cout,Cin,3,3] to [Cout][3][3][Cin]. */
+int edv_pack_conv3x3(const float *w_dev, float *wpacked_dev, int32_t Cout, int32_t Cin, void *stream);
+
+/* Encoder self-attention, layers/attention.py:56-69: qkv [F*N, 3*heads*64] as produced by the
+ * qkv linear (columns ordered [3][heads][64]) -> out [F*N, heads*64]. */
+int edv_attn_spatial(const float *qkv_dev, float *out_dev, int32_t F, int32_t N, int32_t heads, void *stream);
+
+/* Temporal attention core, motion_module.py:230-297 + attention.py:182-211: qkv [B*T*P, 3C]
+ * (q|k|v per row, 8 heads), softmax over the T frames of each pixel -> out [B*T*P, C]. */
+int edv_attn_temporal(const float *qkv_dev, float *out_dev, int32_t B, int32_t T, int32_t P, int32_t C, int32_t heads, void *stream);
+
+/* GroupNorm(32 groups) on channels-last x [F,P,C] (motion_module.py:84,110). */
+int edv_groupnorm(const float *x_dev, const float *w_dev, const float *b_dev, float *y_dev, float *stats_dev /* [F*32*2] scratch */,
+                  int32_t F, int32_t P, int32_t C, int32_t groups, float eps, void *stream);
+
+/* GEGLU, attention.py:363-384: y[m, j] = x[m, j] * gelu(x[m, inner + j]), x [M, 2*inner]. */
+int edv_geglu(const float *x_dev, float *y_dev, int64_t M, int32_t inner, void *stream);
+
+/* Bilinear resize, align_corners=True, channels-last [F,H,W,C] -> [F,OH,OW,C]
+ * (every F.interpolate of the model). */
+int edv_bilinear(const float *x_dev, float *y_dev, int32_t F, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void *stream);
+
+/* y[m] = act(x[m,:]·w + b) for the final 1x1 convs; act: 0 none, 2 ReLU, 3 sigmoid, 4 sigmoid(-v). */
+int edv_dot_channels(const float *x_dev, const float *w_dev, const float *b_dev, float *y_dev, int64_t M, int32_t C, int32_t act, void *stream);
+
+/* endodav.py:153-155 + patch_embed.py:75-77 staging: bilinear resize (align_corners) of
+ * x [F,3,H,W] to [ih,iw], ImageNet normalisation, and im2col into rows
+ * [F*(ih/14)*(iw/14), 588] ordered (c, ky, kx) like the Conv2d weight. */
+int edv_patchify(const float *x_dev, float *cols_dev, int32_t F, int32_t H, int32_t W, int32_t ih, int32_t iw, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ENDODAV_HIP_H */

@@ -1,0 +1,36 @@
+"""Parity cases shared by the golden generator, the oracle tests and the GPU tests.
+
+Each case = reference constructor kwargs (``models/endodav/endodav.py:53-73``) + a synthetic
+clip shape.  Weights and clips come from ``endodav_amd.synth`` (name-keyed, portable), so a
+fixture only has to hold outputs.
+"""
+from __future__ import annotations
+
+VITS = dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384])
+VITS_SMALL_HEAD = dict(encoder="vits", features=32, out_channels=[32, 32, 64, 64])
+VITL_SMALL_HEAD = dict(encoder="vitl", features=32, out_channels=[32, 64, 64, 64])
+
+# name -> (ctor kwargs, (B, T, H, W) of the input clip, clip kind, store)
+# store: "full" keeps whole outputs; "strided" keeps every 7th pixel of disp 0 + stats.
+CASES = {
+    # --- micro cases: tiny grids, every code path, full outputs stored -----------------
+    "micro_vda_dvlora": (dict(VITS_SMALL_HEAD, image_shape=(42, 56), lora_type="dvlora", disable_conv_head=True), (1, 3, 42, 56), "uniform", "full"),
+    "micro_vda_lora_b2": (dict(VITS_SMALL_HEAD, image_shape=(42, 42), lora_type="lora", disable_conv_head=True), (2, 2, 42, 42), "uniform", "full"),
+    "micro_conv_dvlora": (dict(VITS_SMALL_HEAD, image_shape=(42, 56), lora_type="dvlora"), (1, 3, 42, 56), "uniform", "full"),
+    "micro_conv_invsig_ssb": (dict(VITS_SMALL_HEAD, image_shape=(42, 56), lora_type="ssb", inv_sigmoid=True), (1, 2, 42, 56), "tissue", "full"),
+    "micro_vda_none_outsig": (dict(VITS_SMALL_HEAD, image_shape=(42, 42), lora_type="none", disable_conv_head=True, out_sigmoid=True), (1, 4, 42, 42), "uniform", "full"),
+    "micro_vda_nocls": (dict(VITS_SMALL_HEAD, image_shape=(42, 56), lora_type="dvlora", disable_conv_head=True, include_cls_token=False), (1, 2, 42, 56), "uniform", "full"),
+    "micro_vda_temporal_lora": (dict(VITS_SMALL_HEAD, image_shape=(42, 56), lora_type="lora", disable_conv_head=True, temporal_lora=True), (1, 3, 42, 56), "uniform", "full"),
+    "micro_resize_in": (dict(VITS_SMALL_HEAD, image_shape=(42, 56), lora_type="dvlora", disable_conv_head=True), (1, 2, 64, 80), "tissue", "full"),
+    "micro_t1": (dict(VITS_SMALL_HEAD, image_shape=(42, 56), lora_type="dvlora", disable_conv_head=True), (1, 1, 42, 56), "uniform", "full"),
+    "micro_t32": (dict(VITS_SMALL_HEAD, image_shape=(42, 42), lora_type="dvlora", disable_conv_head=True), (1, 32, 42, 42), "tissue", "full"),
+    "micro_vitl": (dict(VITL_SMALL_HEAD, image_shape=(42, 56), lora_type="dvlora", disable_conv_head=True), (1, 2, 42, 56), "uniform", "full"),
+    # --- reference default geometry (224x280 from 256x320 frames, trainer_end_to_end_video.py:61)
+    "vits_224x280_t2": (dict(VITS, image_shape=(224, 280), lora_type="dvlora", disable_conv_head=True), (1, 2, 256, 320), "tissue", "strided"),
+    "vits_224x280_conv_t2": (dict(VITS, image_shape=(224, 280), lora_type="dvlora"), (1, 2, 256, 320), "tissue", "strided"),
+    # --- BASELINE config 1: ViT-S 518x518 T=4 -------------------------------------------
+    "vits_518_t4": (dict(VITS, image_shape=(518, 518), lora_type="dvlora", disable_conv_head=True), (1, 4, 518, 518), "uniform", "strided"),
+}
+
+# cases replayed by the (CPU) oracle test on every run; the 518 case takes ~5 s
+STAGE_KEYS = ("tokens", "block0", "tap0", "tap3", "mm0", "mm1", "path4", "path3", "path2", "path1")

@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the imported reference.
+
+CONTAINER-ONLY: needs /root/reference (read-only, never shipped).  Run as
+
+    python tests/golden/make_golden.py [case ...]
+
+What it does, per case of ``cases.CASES``:
+  1. imports the reference's ``models.endodav`` (with in-memory stand-ins for the four
+     third-party packages absent from this image, see ``_install_standins``);
+  2. constructs the reference model, overwrites every parameter from
+     ``endodav_amd.synth`` (name-keyed), runs the reference forward on a synthetic clip;
+  3. runs ``oracle.endodav_oracle.forward`` on the very same state dict and input and
+     REFUSES to write a fixture unless the oracle matches the reference tightly;
+  4. stores the reference outputs (whole, or strided samples + per-frame statistics) as
+     ``<case>.npz`` (plain float arrays, no pickles).
+
+The stand-ins supply only what the reference imports at module scope and the one
+arithmetic op on the forward path, torchvision's ``Normalize`` = (x-mean)/std
+(reference models/endodav/endodav.py:88,155).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REFERENCE = "/root/reference"
+
+
+def _install_standins() -> None:
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    class Normalize:
+        def __init__(self, mean, std):
+            self.mean, self.std = mean, std
+
+        def __call__(self, x):
+            m = torch.tensor(self.mean, dtype=x.dtype, device=x.device)[:, None, None]
+            s = torch.tensor(self.std, dtype=x.dtype, device=x.device)[:, None, None]
+            return (x - m) / s
+
+    tvt.Compose, tvt.Normalize = Compose, Normalize
+    tv.transforms = tvt
+    sys.modules["torchvision"], sys.modules["torchvision.transforms"] = tv, tvt
+
+    cv2 = types.ModuleType("cv2")
+    cv2.INTER_CUBIC, cv2.INTER_AREA, cv2.INTER_NEAREST = 2, 3, 0
+    sys.modules["cv2"] = cv2
+
+    ed = types.ModuleType("easydict")
+
+    class EasyDict(dict):
+        def __getattr__(self, k):
+            return self[k]
+
+    ed.EasyDict = EasyDict
+    sys.modules["easydict"] = ed
+
+    fv, fvn, fvw = types.ModuleType("fvcore"), types.ModuleType("fvcore.nn"), types.ModuleType("fvcore.nn.weight_init")
+
+    def c2_msra_fill(m):  # only reached when residual_block_indexes != []; weights are overwritten anyway
+        torch.nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+
+    fvw.c2_msra_fill = c2_msra_fill
+    fvn.weight_init, fv.nn = fvw, fvn
+    sys.modules["fvcore"], sys.modules["fvcore.nn"], sys.modules["fvcore.nn.weight_init"] = fv, fvn, fvw
+
+
+def load_reference():
+    _install_standins()
+    sys.path.insert(0, REFERENCE)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        import models.endodav as ref  # noqa
+    return ref
+
+
+def stats(a: np.ndarray) -> np.ndarray:
+    """per-frame [mean, min, max, l2] in float64."""
+    f = a.reshape(a.shape[0], -1).astype(np.float64)
+    return np.stack([f.mean(1), f.min(1), f.max(1), np.sqrt((f * f).sum(1))], axis=1)
+
+
+def strided(a: np.ndarray, step: int = 7) -> np.ndarray:
+    return np.ascontiguousarray(a[..., ::step, ::step])
+
+
+def main(argv):
+    from endodav_amd import synth
+    from oracle import endodav_oracle as orc
+    from tests.golden.cases import CASES, STAGE_KEYS
+
+    ref = load_reference()
+    names = argv or list(CASES)
+    torch.set_num_threads(8)
+    for name in names:
+        kwargs, (B, T, H, W), kind, store = CASES[name]
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            model = ref.endodav(**kwargs, pretrained_path=None).eval()
+        synth.fill_module_(model)
+        x = torch.from_numpy(synth.synth_clip(B, T, H, W, seed=1, kind=kind))
+        with torch.no_grad():
+            out_ref = model(x)
+        sd = {k: v.detach() for k, v in model.state_dict().items()}
+        cfg = orc.OracleConfig(
+            encoder=kwargs["encoder"], image_shape=tuple(kwargs["image_shape"]), lora_type=kwargs.get("lora_type", "lora"),
+            r=kwargs.get("r", 4), include_cls_token=kwargs.get("include_cls_token", True),
+            disable_conv_head=kwargs.get("disable_conv_head", False), inv_sigmoid=kwargs.get("inv_sigmoid", False),
+            out_sigmoid=kwargs.get("out_sigmoid", False))
+        stages = {}
+        with torch.no_grad():
+            out_orc = orc.forward(sd, x, cfg, stages)
+        worst = 0.0
+        for k in out_ref:
+            a, b = out_ref[k], out_orc[k]
+            assert a.shape == b.shape, (name, k, a.shape, b.shape)
+            err = float((a - b).abs().max() / a.abs().max().clamp_min(1e-12))
+            worst = max(worst, err)
+        assert worst < 2e-5, f"{name}: oracle deviates from the reference by {worst:.3e}"
+        nz = float((out_ref[('disp', 0)] > 0).float().mean())
+        payload = {"oracle_vs_reference_maxrel": np.float64(worst)}
+        for k, v in out_ref.items():
+            a = v.numpy()
+            payload[f"disp{k[1]}_stats"] = stats(a)
+            payload[f"disp{k[1]}"] = a if store == "full" else strided(a)
+        for sk in STAGE_KEYS:  # per-stage pins come from the (reference-validated) oracle
+            if sk in stages:
+                a = stages[sk].numpy()
+                payload[f"stage_{sk}_stats"] = stats(a)
+                if store == "strided":
+                    flat = a.reshape(a.shape[0], -1)
+                    payload[f"stage_{sk}_sample"] = np.ascontiguousarray(flat[:, ::997][:, :256])
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **payload)
+        print(f"{name}: oracle-vs-reference max rel {worst:.2e}; disp0 nonzero frac {nz:.3f}; "
+              f"disp0 mean {float(out_ref[('disp', 0)].mean()):.4f}; wrote {os.path.getsize(path)} B")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])

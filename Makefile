@@ -1,0 +1,23 @@
+# Builds the gfx950 shared library in-tree (the .so travels to the GPU box with the snapshot).
+HIPCC    ?= /opt/rocm/bin/hipcc
+ARCH     ?= gfx950
+CSRC     := endodav_amd/csrc
+OUT      := endodav_amd/lib/libendodav_hip.so
+SRCS     := $(CSRC)/gemm.hip $(CSRC)/attn_spatial.hip $(CSRC)/norms.hip $(CSRC)/temporal.hip \
+            $(CSRC)/resample.hip $(CSRC)/prep.hip $(CSRC)/engine.hip $(CSRC)/api.hip
+OBJS     := $(SRCS:$(CSRC)/%.hip=build/%.o)
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-gpu-rdc
+
+all: $(OUT)
+
+build/%.o: $(CSRC)/%.hip $(CSRC)/ops.hpp $(CSRC)/common.hpp include/endodav_hip.h
+	@mkdir -p build
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+
+$(OUT): $(OBJS)
+	@mkdir -p endodav_amd/lib
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $(OBJS)
+
+clean:
+	rm -rf build $(OUT)
+.PHONY: all clean

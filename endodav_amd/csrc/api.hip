@@ -1,0 +1,91 @@
+// extern "C" per-kernel entry points declared in include/endodav_hip.h (unit tests, micro-benchmarks).
+#include "../../include/endodav_hip.h"
+#include "ops.hpp"
+
+using namespace edv;
+
+extern "C" {
+
+int edv_layernorm(const float *x_dev, const float *w_dev, const float *b_dev, float *y_dev, int64_t rows, int32_t dim, float eps,
+                  const float *pe_dev, int32_t rows_per_frame, int32_t T, void *stream) {
+    return layernorm(x_dev, identity_map(), w_dev, b_dev, y_dev, identity_map(), rows, dim, eps, pe_dev, rows_per_frame, T, (hipStream_t)stream);
+}
+
+int edv_gemm(const float *A_dev, const float *W_dev, float *C_dev, int64_t M, int32_t N, int32_t K, const float *bias_dev, int32_t act,
+             const float *gamma_dev, const float *R_dev, void *stream) {
+    GemmDesc g;
+    g.A = A_dev; g.lda = K; g.W = W_dev; g.ldw = K; g.C = C_dev; g.ldc = N; g.M = M; g.N = N; g.K = K;
+    g.bias = bias_dev; g.act = act; g.gamma = gamma_dev; g.R1 = R_dev; g.ldr1 = N;
+    EDV_CHECK(act >= ACT_NONE && act <= ACT_RELU, "act must be 0, 1 or 2");
+    return gemm(g, (hipStream_t)stream);
+}
+
+int edv_conv3x3(const float *x_dev, const float *wpacked_dev, const float *bias_dev, float *y_dev, int32_t F, int32_t H, int32_t W, int32_t Cin,
+                int32_t Cout, int32_t stride, int32_t pre_relu, int32_t post_relu, const float *R1_dev, const float *R2_dev, void *stream) {
+    EDV_CHECK(F > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "empty problem");
+    EDV_CHECK(stride == 1 || stride == 2, "stride must be 1 or 2");
+    GemmDesc g;
+    const int OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+    g.A = x_dev; g.W = wpacked_dev; g.ldw = 9 * Cin; g.C = y_dev; g.ldc = Cout; g.M = (long long)F * OH * OW; g.N = Cout; g.K = 9 * Cin;
+    g.bias = bias_dev; g.act = post_relu ? ACT_RELU : ACT_NONE; g.R1 = R1_dev; g.ldr1 = Cout; g.R2 = R2_dev; g.ldr2 = Cout;
+    g.loader = LOAD_CONV3; g.cH = H; g.cW = W; g.cC = Cin; g.cOH = OH; g.cOW = OW; g.cS = stride; g.pre_relu = pre_relu ? 1 : 0;
+    return gemm(g, (hipStream_t)stream);
+}
+
+int edv_pack_conv3x3(const float *w_dev, float *wpacked_dev, int32_t Cout, int32_t Cin, void *stream) {
+    return pack_conv3x3(w_dev, wpacked_dev, Cout, Cin, (hipStream_t)stream);
+}
+
+int edv_conv_transpose(const float *x_dev, const float *w_dev, const float *b_dev, float *wpack_dev, float *bpack_dev, float *y_dev, int32_t F, int32_t h,
+              int32_t w, int32_t C, int32_t s, void *stream) {
+    EDV_CHECK(F > 0 && h > 0 && w > 0 && C > 0 && s > 0, "empty problem");
+    EDV_TRY(pack_convT(w_dev, wpack_dev, b_dev, bpack_dev, C, C, s, (hipStream_t)stream));
+    GemmDesc g;
+    g.A = x_dev; g.lda = C; g.W = wpack_dev; g.ldw = C; g.C = y_dev; g.ldc = C; g.M = (long long)F * h * w; g.N = s * s * C; g.K = C;
+    g.bias = bpack_dev; g.store = STORE_SHUFFLE; g.ps_s = s; g.ps_C = C; g.ps_h = h; g.ps_w = w;
+    return gemm(g, (hipStream_t)stream);
+}
+
+int edv_attn_spatial(const float *qkv_dev, float *out_dev, int32_t F, int32_t N, int32_t heads, void *stream) {
+    return attn_spatial(qkv_dev, out_dev, F, N, heads, (hipStream_t)stream);
+}
+
+int edv_attn_temporal(const float *qkv_dev, float *out_dev, int32_t B, int32_t T, int32_t P, int32_t C, int32_t heads, void *stream) {
+    return attn_temporal(qkv_dev, out_dev, B, T, P, C, heads, (hipStream_t)stream);
+}
+
+int edv_groupnorm(const float *x_dev, const float *w_dev, const float *b_dev, float *y_dev, float *stats_dev, int32_t F, int32_t P, int32_t C,
+                  int32_t groups, float eps, void *stream) {
+    return groupnorm(x_dev, w_dev, b_dev, y_dev, stats_dev, F, P, C, groups, eps, (hipStream_t)stream);
+}
+
+int edv_geglu(const float *x_dev, float *y_dev, int64_t M, int32_t inner, void *stream) { return geglu(x_dev, y_dev, M, inner, (hipStream_t)stream); }
+
+int edv_bilinear(const float *x_dev, float *y_dev, int32_t F, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void *stream) {
+    return bilinear(x_dev, y_dev, F, H, W, C, OH, OW, ACT_NONE, (hipStream_t)stream);
+}
+
+int edv_dot_channels(const float *x_dev, const float *w_dev, const float *b_dev, float *y_dev, int64_t M, int32_t C, int32_t act, void *stream) {
+    EDV_CHECK(act == ACT_NONE || act == ACT_RELU || act == ACT_SIGMOID || act == ACT_SIGMOID_NEG, "act must be 0, 2, 3 or 4");
+    return dot_channels(x_dev, w_dev, b_dev, y_dev, M, C, act, (hipStream_t)stream);
+}
+
+int edv_patchify(const float *x_dev, float *cols_dev, int32_t F, int32_t H, int32_t W, int32_t ih, int32_t iw, void *stream) {
+    return patchify(x_dev, cols_dev, F, H, W, ih, iw, (hipStream_t)stream);
+}
+
+int edv_bicubic_pos(const float *grid_dev, float *out_dev, int32_t S, int32_t D, int32_t oh, int32_t ow, double scale_h, double scale_w, void *stream) {
+    EDV_CHECK(scale_h > 0 && scale_w > 0, "scale factors must be positive");
+    return bicubic_pos(grid_dev, out_dev, S, D, oh, ow, (float)(1.0 / scale_h), (float)(1.0 / scale_w), (hipStream_t)stream);
+}
+
+int edv_resize_bicubic(const float *x_dev, float *y_dev, int32_t planes, int32_t H, int32_t W, int32_t OH, int32_t OW, void *stream) {
+    return resize_bicubic(x_dev, y_dev, planes, H, W, OH, OW, (hipStream_t)stream);
+}
+
+int edv_fold_lora(const float *W_dev, const float *A_dev, const float *B_dev, const float *U_dev, const float *V_dev, float scale, float *out_dev,
+                  int32_t nout, int32_t nin, int32_t r, void *stream) {
+    return fold_lora(W_dev, A_dev, B_dev, U_dev, V_dev, scale, out_dev, nout, nin, r, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,701 @@
+// The forward engine: edv_create / edv_bind_param / edv_prepare / edv_forward.
+//
+// Sequences EndoDAV's per-clip forward (reference models/endodav/endodav.py:150-160) as ~25 kernel
+// launches per encoder block + ~120 for the DPT head on one HIP stream.  No host sync inside a
+// forward once the workspace for a clip geometry exists.  Layouts: encoder activations are
+// tokens-major [frames*tokens, D]; head activations channels-last [frames, h, w, C], so that
+//   - the 1x1 "projects" convs, proj_in/out and every Linear are plain GEMMs on the same buffers,
+//   - the five NCHW<->NLC permutes per motion module (motion_module.py:105,112,121,124,232,295)
+//     and the tap permute (dpt_pyramid.py:61) vanish,
+//   - temporal attention reaches the frame axis by a constant address stride.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/endodav_hip.h"
+#include "ops.hpp"
+
+namespace edv {
+static thread_local std::string g_err;
+void set_error(const std::string &m) { g_err = m; }
+const char *get_error() { return g_err.c_str(); }
+}  // namespace edv
+
+using namespace edv;
+
+struct Param {
+    const float *p;
+    std::vector<int64_t> shape;
+    long long numel() const {
+        long long n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+};
+struct Buf {
+    float *p = nullptr;
+    size_t cap = 0;  // floats
+};
+
+struct edv_ctx {
+    edv_config cfg{};
+    std::unordered_map<std::string, Param> params;
+    std::unordered_map<std::string, Buf> packed;  // derived weights, owned
+    std::unordered_map<std::string, Buf> ws;      // activations, owned
+    bool prepared = false;
+    bool capture = false;
+    int launches = 0;
+    size_t bytes = 0;
+    // geometry of the last forward (for edv_stage_copy)
+    int F = 0, T = 0, ph = 0, pw = 0, ntok = 0;
+    std::unordered_map<std::string, std::pair<const float *, size_t>> stages;
+};
+
+namespace {
+
+int alloc_buf(edv_ctx *c, std::unordered_map<std::string, Buf> &pool, const std::string &name, size_t n, hipStream_t st, float **out) {
+    Buf &b = pool[name];
+    if (b.cap < n) {
+        if (b.p) {
+            EDV_HIP(hipStreamSynchronize(st));  // kernels in flight may still read the old block
+            EDV_HIP(hipFree(b.p));
+            c->bytes -= b.cap * sizeof(float);
+            b.p = nullptr;
+            b.cap = 0;
+        }
+        void *p = nullptr;
+        EDV_HIP(hipMalloc(&p, n * sizeof(float)));
+        b.p = (float *)p;
+        b.cap = n;
+        c->bytes += n * sizeof(float);
+    }
+    *out = b.p;
+    return 0;
+}
+
+struct Run {
+    edv_ctx *c;
+    hipStream_t st;
+    const edv_config &cfg;
+    int D, depth, heads, Fe;
+    int F = 0, B = 0, T = 0, ph = 0, pw = 0, P0 = 0, ntok = 0, c0 = 0;
+
+    Run(edv_ctx *ctx, hipStream_t s) : c(ctx), st(s), cfg(ctx->cfg) {
+        D = cfg.embed_dim;
+        depth = cfg.depth;
+        heads = cfg.num_heads;
+        Fe = cfg.features;
+    }
+
+    // ---- lookup helpers -------------------------------------------------------------------
+    int param(const std::string &name, const float **out, int ndim_expect = -1) {
+        auto it = c->params.find(name);
+        EDV_CHECK(it != c->params.end(), "parameter not bound: " + name);
+        if (ndim_expect >= 0) EDV_CHECK((int)it->second.shape.size() == ndim_expect, "unexpected rank for " + name);
+        *out = it->second.p;
+        return 0;
+    }
+    bool has(const std::string &name) const { return c->params.count(name) != 0; }
+    int packedw(const std::string &name, const float **out) {
+        auto it = c->packed.find(name);
+        EDV_CHECK(it != c->packed.end() && it->second.p, "packed weight missing (edv_prepare not run?): " + name);
+        *out = it->second.p;
+        return 0;
+    }
+    int wsbuf(const std::string &name, size_t n, float **out) { return alloc_buf(c, c->ws, name, n, st, out); }
+    int pk(const std::string &name, size_t n, float **out) { return alloc_buf(c, c->packed, name, n, st, out); }
+
+    // ---- op wrappers ----------------------------------------------------------------------
+    int linear(const float *A, long long M, int K, const float *W, int N, const float *bias, float *C, int act = ACT_NONE,
+               const float *gamma = nullptr, const float *R1 = nullptr) {
+        GemmDesc g;
+        g.A = A; g.lda = K; g.W = W; g.ldw = K; g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K;
+        g.bias = bias; g.act = act; g.gamma = gamma; g.R1 = R1; g.ldr1 = N;
+        c->launches++;
+        return gemm(g, st);
+    }
+    int conv3(const float *x, int H, int W, int Cin, const float *wp, const float *bias, int Cout, int stride, float *y, bool pre_relu,
+              int act = ACT_NONE, const float *R1 = nullptr, const float *R2 = nullptr) {
+        GemmDesc g;
+        const int OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+        g.A = x; g.W = wp; g.ldw = 9 * Cin; g.C = y; g.ldc = Cout; g.M = (long long)F * OH * OW; g.N = Cout; g.K = 9 * Cin;
+        g.bias = bias; g.act = act; g.R1 = R1; g.ldr1 = Cout; g.R2 = R2; g.ldr2 = Cout;
+        g.loader = LOAD_CONV3; g.cH = H; g.cW = W; g.cC = Cin; g.cOH = OH; g.cOW = OW; g.cS = stride; g.pre_relu = pre_relu ? 1 : 0;
+        c->launches++;
+        return gemm(g, st);
+    }
+    int ln(const float *x, RowMap im, const std::string &prefix, float *y, long long rows, int dim, float eps, const float *pe = nullptr,
+           int rpf = 0, int TT = 0) {
+        const float *w, *b;
+        EDV_TRY(param(prefix + ".weight", &w));
+        EDV_TRY(param(prefix + ".bias", &b));
+        c->launches++;
+        return layernorm(x, im, w, b, y, identity_map(), rows, dim, eps, pe, rpf, TT, st);
+    }
+
+    // ---- weight packing (edv_prepare) -----------------------------------------------------
+    int fold_linear(const std::string &p, bool lora_here) {
+        // result registered under packed[p + ".weight"]; a plain pointer alias when no LoRA applies
+        const float *W;
+        EDV_TRY(param(p + ".weight", &W, 2));
+        const Param &pw_ = c->params[p + ".weight"];
+        const int nout = (int)pw_.shape[0], nin = (int)pw_.shape[1];
+        if (!lora_here || cfg.lora_type == EDV_LORA_NONE || !has(p + ".lora_A")) return 0;
+        float *out;
+        EDV_TRY(pk(p + ".weight", (size_t)nout * nin, &out));
+        const float *A, *Bm;
+        EDV_TRY(param(p + ".lora_A", &A));
+        EDV_TRY(param(p + ".lora_B", &Bm));
+        const int r = cfg.lora_rank;
+        switch (cfg.lora_type) {
+            case EDV_LORA_LORA:  // lora_alpha = 2r  (endodav.py:111-112)
+                return fold_lora(W, A, Bm, nullptr, nullptr, 2.0f, out, nout, nin, r, st);
+            case EDV_LORA_DVLORA: {  // lora_alpha = r  (endodav.py:108-109)
+                const float *U, *V;
+                EDV_TRY(param(p + ".lora_U", &U));
+                EDV_TRY(param(p + ".lora_V", &V));
+                return fold_lora(W, A, Bm, U, V, 1.0f, out, nout, nin, r, st);
+            }
+            case EDV_LORA_SSB:
+                return fold_ssb(W, A, Bm, out, nout, nin, st);
+            case EDV_LORA_DASH: {
+                EDV_TRY(fold_lora(W, A, Bm, nullptr, nullptr, 2.0f, out, nout, nin, r, st));
+                if (cfg.dash_active) {
+                    const float *Ut, *idx, *Vt;
+                    EDV_TRY(param(p + ".weight_u_top", &Ut));
+                    EDV_TRY(param(p + ".lora_index", &idx));
+                    EDV_TRY(param(p + ".weight_vt_top", &Vt));
+                    const int ri = (int)c->params[p + ".lora_index"].shape[0];
+                    return fold_dash(Ut, idx, Vt, out, nout, nin, ri, st);
+                }
+                return 0;
+            }
+            default:
+                EDV_CHECK(false, "unknown lora_type");
+        }
+        return 0;
+    }
+    // effective weight of a (possibly folded) linear
+    int lin_w(const std::string &p, const float **out) {
+        auto it = c->packed.find(p + ".weight");
+        if (it != c->packed.end() && it->second.p) {
+            *out = it->second.p;
+            return 0;
+        }
+        return param(p + ".weight", out);
+    }
+    int pack_c3(const std::string &p) {
+        const float *w;
+        EDV_TRY(param(p + ".weight", &w, 4));
+        const Param &q = c->params[p + ".weight"];
+        EDV_CHECK(q.shape[2] == 3 && q.shape[3] == 3, "expected a 3x3 kernel: " + p);
+        float *out;
+        EDV_TRY(pk(p + ".weight", (size_t)q.numel(), &out));
+        return pack_conv3x3(w, out, (int)q.shape[0], (int)q.shape[1], st);
+    }
+
+    int prepare() {
+        c->launches = 0;
+        for (int i = 0; i < depth; ++i) {
+            const std::string b = "pretrained.blocks." + std::to_string(i) + ".mlp.";
+            EDV_TRY(fold_linear(b + "fc1", true));
+            EDV_TRY(fold_linear(b + "fc2", true));
+        }
+        const int *oc = cfg.out_channels;
+        {  // ConvTranspose k=s -> GEMM weights
+            const int ss[2] = {4, 2};
+            for (int j = 0; j < 2; ++j) {
+                const std::string p = "head.resize_layers." + std::to_string(j);
+                const float *w, *b;
+                EDV_TRY(param(p + ".weight", &w, 4));
+                EDV_TRY(param(p + ".bias", &b));
+                float *wo, *bo;
+                EDV_TRY(pk(p + ".weight", (size_t)ss[j] * ss[j] * oc[j] * oc[j], &wo));
+                EDV_TRY(pk(p + ".bias", (size_t)ss[j] * ss[j] * oc[j], &bo));
+                EDV_TRY(pack_convT(w, wo, b, bo, oc[j], oc[j], ss[j], st));
+            }
+        }
+        EDV_TRY(pack_c3("head.resize_layers.3"));
+        for (int j = 1; j <= 4; ++j) EDV_TRY(pack_c3("head.scratch.layer" + std::to_string(j) + "_rn"));
+        for (int j = 1; j <= 4; ++j)
+            for (int u = 1; u <= 2; ++u) {
+                if (j == 4 && u == 1) continue;  // refinenet4.resConfUnit1 is never reached (dpt_pyramid.py:81)
+                const std::string p = "head.scratch.refinenet" + std::to_string(j) + ".resConfUnit" + std::to_string(u);
+                EDV_TRY(pack_c3(p + ".conv1"));
+                EDV_TRY(pack_c3(p + ".conv2"));
+            }
+        if (cfg.conv_head) {
+            for (int k = 1; k <= 4; ++k) {
+                EDV_TRY(pack_c3("head.conv_depth_" + std::to_string(k) + ".head.0"));
+                EDV_TRY(pack_c3("head.conv_depth_" + std::to_string(k) + ".head.2"));
+            }
+        } else {
+            EDV_TRY(pack_c3("head.scratch.output_conv1"));
+            EDV_TRY(pack_c3("head.scratch.output_conv2.0"));
+        }
+        const int mmC[4] = {oc[2], oc[3], Fe, Fe};
+        for (int m = 0; m < 4; ++m) {
+            const std::string tb = "head.motion_modules." + std::to_string(m) + ".temporal_transformer.transformer_blocks.0";
+            const int C = mmC[m];
+            for (int a = 0; a < 2; ++a) {
+                const std::string ab = tb + ".attention_blocks." + std::to_string(a);
+                float *qkvw;
+                EDV_TRY(pk(ab + ".qkv", (size_t)3 * C * C, &qkvw));
+                const char *names[3] = {".to_q.weight", ".to_k.weight", ".to_v.weight"};
+                for (int j = 0; j < 3; ++j) {
+                    const float *w;
+                    EDV_TRY(param(ab + names[j], &w, 2));
+                    EDV_TRY(copy_f32(w, qkvw + (size_t)j * C * C, (long long)C * C, st));
+                }
+            }
+            EDV_TRY(fold_linear(tb + ".ff.net.2", cfg.temporal_lora != 0));
+        }
+        c->prepared = true;
+        return 0;
+    }
+
+    // position table for the current patch grid (vision_transformer.py:186-217)
+    int pos_table(const float **out) {
+        const float *pos;
+        EDV_TRY(param("pretrained.pos_embed", &pos, 3));
+        const int Npos = cfg.pos_tokens - 1;
+        const int npatch = ntok - 1;
+        if (npatch == Npos && cfg.image_h == cfg.image_w) {
+            *out = pos;
+            return 0;
+        }
+        const int S = (int)std::lround(std::sqrt((double)Npos));
+        EDV_CHECK(S * S == Npos, "pos_embed grid is not square");
+        float *tab;
+        EDV_TRY(wsbuf("pos_eff", (size_t)ntok * D, &tab));
+        // ATen receives scale_factor as double and uses float(1/scale) (UpSample.h compute_scales_value)
+        const double sh = ((double)ph + 0.1) / std::sqrt((double)Npos), sw = ((double)pw + 0.1) / std::sqrt((double)Npos);
+        EDV_CHECK((int)std::floor(S * sh) == ph && (int)std::floor(S * sw) == pw, "pos-embed resample size mismatch");
+        if (c0) EDV_TRY(copy_f32(pos, tab, D, st));
+        EDV_TRY(bicubic_pos(pos + D, tab + (size_t)c0 * D, S, D, ph, pw, (float)(1.0 / sh), (float)(1.0 / sw), st));
+        c->launches += 2;
+        *out = tab;
+        return 0;
+    }
+
+    int snapshot(const std::string &name, const float *src, size_t n) {
+        if (c->capture) {
+            float *dst;
+            EDV_TRY(wsbuf("stage." + name, n, &dst));
+            EDV_TRY(copy_f32(src, dst, (long long)n, st));
+            c->stages[name] = {dst, n};
+        }
+        return 0;
+    }
+
+    // ---- motion module, in place on x [F, P, C] channels-last (motion_module.py:102-126,164-177) ----
+    int motion_module(int m, float *x, int P, int C) {
+        const std::string p = "head.motion_modules." + std::to_string(m) + ".temporal_transformer";
+        const std::string tb = p + ".transformer_blocks.0";
+        const long long M = (long long)F * P;
+        float *gn, *h, *hn, *qkv3, *att, *ff1, *ff2, *stats;
+        EDV_TRY(wsbuf("mm.gn", (size_t)M * C, &gn));
+        EDV_TRY(wsbuf("mm.h", (size_t)M * C, &h));
+        EDV_TRY(wsbuf("mm.hn", (size_t)M * C, &hn));
+        EDV_TRY(wsbuf("mm.qkv", (size_t)M * 3 * C, &qkv3));
+        EDV_TRY(wsbuf("mm.att", (size_t)M * C, &att));
+        EDV_TRY(wsbuf("mm.ff1", (size_t)M * 8 * C, &ff1));
+        EDV_TRY(wsbuf("mm.ff2", (size_t)M * 4 * C, &ff2));
+        EDV_TRY(wsbuf("mm.stats", (size_t)F * 32 * 2, &stats));
+        const float *w, *b;
+        EDV_TRY(param(p + ".norm.weight", &w));
+        EDV_TRY(param(p + ".norm.bias", &b));
+        EDV_TRY(groupnorm(x, w, b, gn, stats, F, P, C, 32, 1e-6f, st));
+        c->launches += 2;
+        EDV_TRY(param(p + ".proj_in.weight", &w));
+        EDV_TRY(param(p + ".proj_in.bias", &b));
+        EDV_TRY(linear(gn, M, C, w, C, b, h));
+        for (int a = 0; a < 2; ++a) {
+            const std::string ab = tb + ".attention_blocks." + std::to_string(a);
+            const float *pe;
+            EDV_TRY(param(ab + ".pos_encoder.pe", &pe));
+            EDV_TRY(ln(h, identity_map(), tb + ".norms." + std::to_string(a), hn, M, C, 1e-5f, pe, P, T));
+            const float *wqkv;
+            EDV_TRY(packedw(ab + ".qkv", &wqkv));
+            EDV_TRY(linear(hn, M, C, wqkv, 3 * C, nullptr, qkv3));
+            EDV_TRY(attn_temporal(qkv3, att, B, T, P, C, 8, st));
+            c->launches++;
+            EDV_TRY(param(ab + ".to_out.0.weight", &w));
+            EDV_TRY(param(ab + ".to_out.0.bias", &b));
+            EDV_TRY(linear(att, M, C, w, C, b, h, ACT_NONE, nullptr, h));
+        }
+        EDV_TRY(ln(h, identity_map(), tb + ".ff_norm", hn, M, C, 1e-5f));
+        EDV_TRY(param(tb + ".ff.net.0.proj.weight", &w));
+        EDV_TRY(param(tb + ".ff.net.0.proj.bias", &b));
+        EDV_TRY(linear(hn, M, C, w, 8 * C, b, ff1));
+        EDV_TRY(geglu(ff1, ff2, M, 4 * C, st));
+        c->launches++;
+        EDV_TRY(lin_w(tb + ".ff.net.2", &w));
+        EDV_TRY(param(tb + ".ff.net.2.bias", &b));
+        EDV_TRY(linear(ff2, M, 4 * C, w, C, b, h, ACT_NONE, nullptr, h));
+        EDV_TRY(param(p + ".proj_out.weight", &w));
+        EDV_TRY(param(p + ".proj_out.bias", &b));
+        EDV_TRY(linear(h, M, C, w, C, b, x, ACT_NONE, nullptr, x));
+        return 0;
+    }
+
+    // ---- FeatureFusionBlock (util/blocks.py:135-162); x, skip: [F,h,w,Fe]; out: [F,oh,ow,Fe] ----
+    // The 1x1 out_conv is applied BEFORE the bilinear upsample: both are linear, the interpolation
+    // weights sum to one, so conv1x1(up(x)) == up(conv1x1(x)) exactly in real arithmetic, at 1/4 of
+    // the GEMM work.
+    int fusion(int j, const float *x, const float *skip, int h, int w, int oh, int ow, float *out) {
+        const std::string p = "head.scratch.refinenet" + std::to_string(j);
+        const size_t n = (size_t)F * h * w * Fe;
+        float *t1, *t2, *s;
+        EDV_TRY(wsbuf("fu.t1", n, &t1));
+        EDV_TRY(wsbuf("fu.t2", n, &t2));
+        const float *w1, *b1, *w2, *b2;
+        const float *cur = x;
+        if (skip) {
+            EDV_TRY(wsbuf("fu.s", n, &s));
+            EDV_TRY(packedw(p + ".resConfUnit1.conv1.weight", &w1));
+            EDV_TRY(param(p + ".resConfUnit1.conv1.bias", &b1));
+            EDV_TRY(packedw(p + ".resConfUnit1.conv2.weight", &w2));
+            EDV_TRY(param(p + ".resConfUnit1.conv2.bias", &b2));
+            EDV_TRY(conv3(skip, h, w, Fe, w1, b1, Fe, 1, t1, true));
+            // s = x + rcu1(skip) = x + skip + conv2(relu(t1)): both adds ride the conv2 epilogue
+            // (skip_add at util/blocks.py:90 and :146)
+            EDV_TRY(conv3(t1, h, w, Fe, w2, b2, Fe, 1, s, true, ACT_NONE, skip, x));
+            cur = s;
+        }
+        EDV_TRY(packedw(p + ".resConfUnit2.conv1.weight", &w1));
+        EDV_TRY(param(p + ".resConfUnit2.conv1.bias", &b1));
+        EDV_TRY(packedw(p + ".resConfUnit2.conv2.weight", &w2));
+        EDV_TRY(param(p + ".resConfUnit2.conv2.bias", &b2));
+        EDV_TRY(conv3(cur, h, w, Fe, w1, b1, Fe, 1, t1, true));
+        EDV_TRY(conv3(t1, h, w, Fe, w2, b2, Fe, 1, t2, true, ACT_NONE, cur, nullptr));
+        const float *wo, *bo;
+        EDV_TRY(param(p + ".out_conv.weight", &wo));
+        EDV_TRY(param(p + ".out_conv.bias", &bo));
+        EDV_TRY(linear(t2, (long long)F * h * w, Fe, wo, Fe, bo, t1));
+        EDV_TRY(bilinear(t1, out, F, h, w, Fe, oh, ow, ACT_NONE, st));
+        c->launches++;
+        return 0;
+    }
+
+    int forward(const float *x, int B_, int T_, int H, int W, float *const disp[4]) {
+        B = B_; T = T_; F = B * T;
+        ph = cfg.image_h / 14; pw = cfg.image_w / 14; P0 = ph * pw;
+        c0 = cfg.include_cls_token ? 1 : 0;
+        ntok = P0 + c0;
+        c->launches = 0;
+        c->stages.clear();
+        c->F = F; c->T = T; c->ph = ph; c->pw = pw; c->ntok = ntok;
+        const long long MT = (long long)F * ntok;
+        const int *oc = cfg.out_channels;
+
+        // ---------------- encoder ----------------
+        float *cols, *xt, *xn, *qkv, *att, *hid;
+        EDV_TRY(wsbuf("cols", (size_t)F * P0 * 588, &cols));
+        EDV_TRY(wsbuf("xt", (size_t)MT * D, &xt));
+        EDV_TRY(wsbuf("xn", (size_t)MT * D, &xn));
+        EDV_TRY(wsbuf("qkv", (size_t)MT * 3 * D, &qkv));
+        EDV_TRY(wsbuf("att", (size_t)MT * D, &att));
+        EDV_TRY(wsbuf("hid", (size_t)MT * 4 * D, &hid));
+        float *tap[4];
+        for (int j = 0; j < 4; ++j) EDV_TRY(wsbuf("tap" + std::to_string(j), (size_t)F * P0 * D, &tap[j]));
+
+        const float *pos;
+        EDV_TRY(pos_table(&pos));
+        EDV_TRY(patchify(x, cols, F, H, W, cfg.image_h, cfg.image_w, st));
+        c->launches++;
+        {
+            const float *w, *b;
+            EDV_TRY(param("pretrained.patch_embed.proj.weight", &w, 4));
+            EDV_TRY(param("pretrained.patch_embed.proj.bias", &b));
+            GemmDesc g;
+            g.A = cols; g.lda = 588; g.W = w; g.ldw = 588; g.C = xt; g.ldc = D; g.M = (long long)F * P0; g.N = D; g.K = 588;
+            g.bias = b;
+            g.c_map = RowMap{P0, ntok, c0};
+            g.R1 = pos; g.ldr1 = D; g.r1_map = RowMap{P0, 0, c0};
+            EDV_TRY(gemm(g, st));
+            c->launches++;
+            if (c0) {
+                const float *cls;
+                EDV_TRY(param("pretrained.cls_token", &cls));
+                EDV_TRY(cls_rows(cls, pos, xt, F, ntok, D, st));
+                c->launches++;
+            }
+        }
+        EDV_TRY(snapshot("tokens", xt, (size_t)MT * D));
+
+        int tapj = 0;
+        for (int i = 0; i < depth; ++i) {
+            const std::string bp = "pretrained.blocks." + std::to_string(i);
+            const float *w, *b, *gam;
+            EDV_TRY(ln(xt, identity_map(), bp + ".norm1", xn, MT, D, 1e-6f));
+            EDV_TRY(param(bp + ".attn.qkv.weight", &w));
+            EDV_TRY(param(bp + ".attn.qkv.bias", &b));
+            EDV_TRY(linear(xn, MT, D, w, 3 * D, b, qkv));
+            EDV_TRY(attn_spatial(qkv, att, F, ntok, heads, st));
+            c->launches++;
+            EDV_TRY(param(bp + ".attn.proj.weight", &w));
+            EDV_TRY(param(bp + ".attn.proj.bias", &b));
+            EDV_TRY(param(bp + ".ls1.gamma", &gam));
+            EDV_TRY(linear(att, MT, D, w, D, b, xt, ACT_NONE, gam, xt));
+            EDV_TRY(ln(xt, identity_map(), bp + ".norm2", xn, MT, D, 1e-6f));
+            EDV_TRY(lin_w(bp + ".mlp.fc1", &w));
+            EDV_TRY(param(bp + ".mlp.fc1.bias", &b));
+            EDV_TRY(linear(xn, MT, D, w, 4 * D, b, hid, ACT_GELU));
+            EDV_TRY(lin_w(bp + ".mlp.fc2", &w));
+            EDV_TRY(param(bp + ".mlp.fc2.bias", &b));
+            EDV_TRY(param(bp + ".ls2.gamma", &gam));
+            EDV_TRY(linear(hid, MT, 4 * D, w, D, b, xt, ACT_NONE, gam, xt));
+            if (i == 0) EDV_TRY(snapshot("block0", xt, (size_t)MT * D));
+            if (tapj < 4 && i == cfg.taps[tapj]) {
+                // final norm on the tap, cls row dropped (vision_transformer.py:317-321)
+                EDV_TRY(ln(xt, RowMap{P0, ntok, c0}, "pretrained.norm", tap[tapj], (long long)F * P0, D, 1e-6f));
+                c->stages["tap" + std::to_string(tapj)] = {tap[tapj], (size_t)F * P0 * D};
+                ++tapj;
+            }
+        }
+        EDV_CHECK(tapj == 4, "taps must be increasing block indices < depth");
+
+        // ---------------- DPT head: reassemble ----------------
+        const long long MP = (long long)F * P0;
+        const int h1 = 4 * ph, w1 = 4 * pw, h2 = 2 * ph, w2 = 2 * pw, h3 = ph, w3 = pw, h4 = (ph - 1) / 2 + 1, w4 = (pw - 1) / 2 + 1;
+        float *pj, *l1, *l2, *l3, *l4;
+        EDV_TRY(wsbuf("l1", (size_t)F * h1 * w1 * oc[0], &l1));
+        EDV_TRY(wsbuf("l2", (size_t)F * h2 * w2 * oc[1], &l2));
+        EDV_TRY(wsbuf("l3", (size_t)F * h3 * w3 * oc[2], &l3));
+        EDV_TRY(wsbuf("l4", (size_t)F * h4 * w4 * oc[3], &l4));
+        {
+            int mx = oc[0];
+            for (int j = 1; j < 4; ++j) mx = oc[j] > mx ? oc[j] : mx;
+            EDV_TRY(wsbuf("pj", (size_t)MP * mx, &pj));
+        }
+        for (int j = 0; j < 4; ++j) {
+            const std::string pp = "head.projects." + std::to_string(j);
+            const float *w, *b;
+            EDV_TRY(param(pp + ".weight", &w, 4));
+            EDV_TRY(param(pp + ".bias", &b));
+            float *dst = (j == 2) ? l3 : pj;
+            EDV_TRY(linear(tap[j], MP, D, w, oc[j], b, dst));
+            if (j < 2) {
+                const int s = j == 0 ? 4 : 2;
+                const std::string rp = "head.resize_layers." + std::to_string(j);
+                const float *wt, *bt;
+                EDV_TRY(packedw(rp + ".weight", &wt));
+                EDV_TRY(packedw(rp + ".bias", &bt));
+                GemmDesc g;
+                g.A = pj; g.lda = oc[j]; g.W = wt; g.ldw = oc[j]; g.C = j == 0 ? l1 : l2; g.M = MP; g.N = s * s * oc[j]; g.K = oc[j];
+                g.bias = bt; g.store = STORE_SHUFFLE; g.ps_s = s; g.ps_C = oc[j]; g.ps_h = ph; g.ps_w = pw; g.ldc = oc[j];
+                EDV_TRY(gemm(g, st));
+                c->launches++;
+            } else if (j == 3) {
+                const float *wc, *bc;
+                EDV_TRY(packedw("head.resize_layers.3.weight", &wc));
+                EDV_TRY(param("head.resize_layers.3.bias", &bc));
+                EDV_TRY(conv3(pj, ph, pw, oc[3], wc, bc, oc[3], 2, l4, false));
+            }
+        }
+        EDV_TRY(motion_module(0, l3, h3 * w3, oc[2]));
+        EDV_TRY(motion_module(1, l4, h4 * w4, oc[3]));
+        c->stages["mm0"] = {l3, (size_t)F * h3 * w3 * oc[2]};
+        c->stages["mm1"] = {l4, (size_t)F * h4 * w4 * oc[3]};
+
+        float *r1, *r2, *r3, *r4;
+        EDV_TRY(wsbuf("r1", (size_t)F * h1 * w1 * Fe, &r1));
+        EDV_TRY(wsbuf("r2", (size_t)F * h2 * w2 * Fe, &r2));
+        EDV_TRY(wsbuf("r3", (size_t)F * h3 * w3 * Fe, &r3));
+        EDV_TRY(wsbuf("r4", (size_t)F * h4 * w4 * Fe, &r4));
+        {
+            const float *w;
+            EDV_TRY(packedw("head.scratch.layer1_rn.weight", &w));
+            EDV_TRY(conv3(l1, h1, w1, oc[0], w, nullptr, Fe, 1, r1, false));
+            EDV_TRY(packedw("head.scratch.layer2_rn.weight", &w));
+            EDV_TRY(conv3(l2, h2, w2, oc[1], w, nullptr, Fe, 1, r2, false));
+            EDV_TRY(packedw("head.scratch.layer3_rn.weight", &w));
+            EDV_TRY(conv3(l3, h3, w3, oc[2], w, nullptr, Fe, 1, r3, false));
+            EDV_TRY(packedw("head.scratch.layer4_rn.weight", &w));
+            EDV_TRY(conv3(l4, h4, w4, oc[3], w, nullptr, Fe, 1, r4, false));
+        }
+        const int h0 = 8 * ph, w0 = 8 * pw;
+        float *p4, *p3, *p2, *p1;
+        EDV_TRY(wsbuf("p4", (size_t)F * h3 * w3 * Fe, &p4));
+        EDV_TRY(wsbuf("p3", (size_t)F * h2 * w2 * Fe, &p3));
+        EDV_TRY(wsbuf("p2", (size_t)F * h1 * w1 * Fe, &p2));
+        EDV_TRY(wsbuf("p1", (size_t)F * h0 * w0 * Fe, &p1));
+        EDV_TRY(fusion(4, r4, nullptr, h4, w4, h3, w3, p4));
+        EDV_TRY(motion_module(2, p4, h3 * w3, Fe));
+        EDV_TRY(fusion(3, p4, r3, h3, w3, h2, w2, p3));
+        EDV_TRY(motion_module(3, p3, h2 * w2, Fe));
+        EDV_TRY(fusion(2, p3, r2, h2, w2, h1, w1, p2));
+        EDV_TRY(fusion(1, p2, r1, h1, w1, h0, w0, p1));
+        c->stages["path4"] = {p4, (size_t)F * h3 * w3 * Fe};
+        c->stages["path3"] = {p3, (size_t)F * h2 * w2 * Fe};
+        c->stages["path2"] = {p2, (size_t)F * h1 * w1 * Fe};
+        c->stages["path1"] = {p1, (size_t)F * h0 * w0 * Fe};
+
+        // ---------------- output heads ----------------
+        if (!cfg.conv_head) {  // VDA head: dpt.py:117-124 + dpt_pyramid.py:88-102
+            const int ih = cfg.image_h, iw = cfg.image_w, Fh = Fe / 2;
+            float *o1, *up, *o2;
+            EDV_TRY(wsbuf("hd.o1", (size_t)F * h0 * w0 * Fh, &o1));
+            EDV_TRY(wsbuf("hd.up", (size_t)F * ih * iw * Fh, &up));
+            EDV_TRY(wsbuf("hd.o2", (size_t)F * ih * iw * 32, &o2));
+            const float *w, *b;
+            EDV_TRY(packedw("head.scratch.output_conv1.weight", &w));
+            EDV_TRY(param("head.scratch.output_conv1.bias", &b));
+            EDV_TRY(conv3(p1, h0, w0, Fe, w, b, Fh, 1, o1, false));
+            EDV_TRY(bilinear(o1, up, F, h0, w0, Fh, ih, iw, ACT_NONE, st));
+            EDV_TRY(packedw("head.scratch.output_conv2.0.weight", &w));
+            EDV_TRY(param("head.scratch.output_conv2.0.bias", &b));
+            EDV_TRY(conv3(up, ih, iw, Fh, w, b, 32, 1, o2, false, ACT_RELU));
+            EDV_TRY(param("head.scratch.output_conv2.2.weight", &w));
+            EDV_TRY(param("head.scratch.output_conv2.2.bias", &b));
+            EDV_TRY(dot_channels(o2, w, b, disp[0], (long long)F * ih * iw, 32, ACT_RELU, st));
+            int sh = ih, sw = iw;
+            for (int k = 1; k < 4; ++k) {  // F.interpolate(scale_factor=0.5): floor(in/2)
+                const int nh = sh / 2, nw = sw / 2;
+                EDV_TRY(bilinear(disp[k - 1], disp[k], F, sh, sw, 1, nh, nw, ACT_NONE, st));
+                sh = nh; sw = nw;
+            }
+            c->launches += 5;
+            if (cfg.out_sigmoid) {
+                sh = ih; sw = iw;
+                for (int k = 0; k < 4; ++k) {
+                    EDV_TRY(sigmoid_inplace(disp[k], (long long)F * sh * sw, st));
+                    sh /= 2; sw /= 2;
+                }
+                c->launches += 4;
+            }
+        } else {  // four HeadDepth heads: endodav/layers.py:206-221 + dpt_pyramid.py:103-109
+            const float *paths[4] = {p1, p2, p3, p4};
+            const int hs[4] = {h0, h1, h2, h3}, wsz[4] = {w0, w1, w2, w3};
+            const int Fh = Fe / 2;
+            float *o1, *up, *o2;
+            EDV_TRY(wsbuf("hd.o1", (size_t)F * h0 * w0 * Fh, &o1));
+            EDV_TRY(wsbuf("hd.up", (size_t)F * 4 * h0 * w0 * Fh, &up));
+            EDV_TRY(wsbuf("hd.o2", (size_t)F * 4 * h0 * w0 * 32, &o2));
+            for (int k = 3; k >= 0; --k) {
+                const std::string hp = "head.conv_depth_" + std::to_string(k + 1) + ".head.";
+                const float *w, *b;
+                EDV_TRY(packedw(hp + "0.weight", &w));
+                EDV_TRY(param(hp + "0.bias", &b));
+                EDV_TRY(conv3(paths[k], hs[k], wsz[k], Fe, w, b, Fh, 1, o1, false));
+                EDV_TRY(bilinear(o1, up, F, hs[k], wsz[k], Fh, 2 * hs[k], 2 * wsz[k], ACT_NONE, st));
+                EDV_TRY(packedw(hp + "2.weight", &w));
+                EDV_TRY(param(hp + "2.bias", &b));
+                EDV_TRY(conv3(up, 2 * hs[k], 2 * wsz[k], Fh, w, b, 32, 1, o2, false, ACT_RELU));
+                EDV_TRY(param(hp + "4.weight", &w));
+                EDV_TRY(param(hp + "4.bias", &b));
+                EDV_TRY(dot_channels(o2, w, b, disp[k], (long long)F * 4 * hs[k] * wsz[k], 32, cfg.inv_sigmoid ? ACT_SIGMOID_NEG : ACT_SIGMOID, st));
+                c->launches += 2;
+            }
+        }
+        return 0;
+    }
+};
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int edv_abi_version(void) { return EDV_ABI_VERSION; }
+const char *edv_last_error(void) { return edv::get_error(); }
+
+int edv_create(const edv_config *cfg, edv_ctx **out) {
+    EDV_CHECK(cfg && out, "null argument");
+    EDV_CHECK(cfg->abi_version == EDV_ABI_VERSION, "ABI version mismatch");
+    EDV_CHECK(cfg->embed_dim > 0 && cfg->num_heads > 0 && cfg->embed_dim == cfg->num_heads * 64, "head dim must be 64");
+    EDV_CHECK(cfg->embed_dim <= 1024, "embed_dim > 1024 unsupported");
+    EDV_CHECK(cfg->depth > 0, "depth");
+    EDV_CHECK(cfg->image_h > 0 && cfg->image_w > 0 && cfg->image_h % 14 == 0 && cfg->image_w % 14 == 0,
+              "image_shape must be a multiple of the 14-pixel patch");
+    EDV_CHECK(cfg->num_frames > 0, "num_frames must be positive");  // dpt_temporal.py:34
+    EDV_CHECK(cfg->features > 0 && cfg->features % 32 == 0, "features must be a multiple of 32 (GroupNorm(32) + 8 heads)");
+    for (int j = 0; j < 4; ++j) EDV_CHECK(cfg->out_channels[j] > 0 && cfg->out_channels[j] % 4 == 0, "out_channels must be multiples of 4");
+    EDV_CHECK(cfg->out_channels[2] % 32 == 0 && cfg->out_channels[3] % 32 == 0, "out_channels[2:] must be multiples of 32");
+    EDV_CHECK(cfg->features <= 1024 && cfg->out_channels[2] <= 1024 && cfg->out_channels[3] <= 1024, "temporal width > 1024 unsupported");
+    EDV_CHECK(cfg->lora_type >= 0 && cfg->lora_type <= EDV_LORA_DASH, "lora_type");
+    for (int j = 0; j < 4; ++j) EDV_CHECK(cfg->taps[j] >= 0 && cfg->taps[j] < cfg->depth && (j == 0 || cfg->taps[j] > cfg->taps[j - 1]), "taps");
+    *out = new edv_ctx();
+    (*out)->cfg = *cfg;
+    return 0;
+}
+
+int edv_destroy(edv_ctx *ctx) {
+    if (!ctx) return 0;
+    hipDeviceSynchronize();
+    for (auto &kv : ctx->packed)
+        if (kv.second.p) hipFree(kv.second.p);
+    for (auto &kv : ctx->ws)
+        if (kv.second.p) hipFree(kv.second.p);
+    delete ctx;
+    return 0;
+}
+
+int edv_bind_param(edv_ctx *ctx, const char *name, const float *data_dev, const int64_t *shape, int32_t ndim) {
+    EDV_CHECK(ctx && name && data_dev && (shape || ndim == 0) && ndim >= 0 && ndim <= 8, "bad argument");
+    EDV_CHECK(((uintptr_t)data_dev % 16) == 0, std::string("parameter not 16-byte aligned: ") + name);
+    Param p;
+    p.p = data_dev;
+    p.shape.assign(shape, shape + ndim);
+    ctx->params[name] = p;
+    ctx->prepared = false;
+    return 0;
+}
+
+int edv_prepare(edv_ctx *ctx, void *stream) {
+    EDV_CHECK(ctx, "null context");
+    Run r(ctx, (hipStream_t)stream);
+    return r.prepare();
+}
+
+int edv_set_capture(edv_ctx *ctx, int on) {
+    EDV_CHECK(ctx, "null context");
+    ctx->capture = on != 0;
+    return 0;
+}
+
+int edv_forward(edv_ctx *ctx, const float *x_dev, int32_t B, int32_t T, int32_t H, int32_t W, float *const disp_dev[4], void *stream) {
+    EDV_CHECK(ctx && x_dev && disp_dev, "null argument");
+    EDV_CHECK(ctx->prepared, "edv_prepare must run after binding parameters");
+    EDV_CHECK(B > 0 && T > 0 && H > 1 && W > 1, "empty clip");
+    // motion_module.py:197: the position table is sliced to T -> size mismatch beyond num_frames
+    EDV_CHECK(T <= ctx->cfg.num_frames, "T exceeds num_frames (temporal_max_len)");
+    EDV_CHECK((long long)B * T <= 65535, "too many frames in one call");
+    for (int k = 0; k < 4; ++k) EDV_CHECK(disp_dev[k], "null output");
+    Run r(ctx, (hipStream_t)stream);
+    return r.forward(x_dev, B, T, H, W, disp_dev);
+}
+
+int edv_output_shape(const edv_ctx *ctx, int32_t scale, int32_t *h, int32_t *w) {
+    EDV_CHECK(ctx && h && w && scale >= 0 && scale < 4, "bad argument");
+    const edv_config &c = ctx->cfg;
+    if (!c.conv_head) {
+        int sh = c.image_h, sw = c.image_w;
+        for (int k = 0; k < scale; ++k) { sh /= 2; sw /= 2; }
+        *h = sh; *w = sw;
+    } else {
+        const int ph = c.image_h / 14, pw = c.image_w / 14;
+        const int mul[4] = {16, 8, 4, 2};
+        *h = ph * mul[scale]; *w = pw * mul[scale];
+    }
+    return 0;
+}
+
+int edv_stage_copy(edv_ctx *ctx, const char *name, float *dst_dev, size_t *n, void *stream) {
+    EDV_CHECK(ctx && name && n, "bad argument");
+    auto it = ctx->stages.find(name);
+    EDV_CHECK(it != ctx->stages.end(), std::string("stage not available (capture off or unknown): ") + name);
+    *n = it->second.second;
+    if (dst_dev) return copy_f32(it->second.first, dst_dev, (long long)it->second.second, (hipStream_t)stream);
+    return 0;
+}
+
+size_t edv_device_bytes(const edv_ctx *ctx) { return ctx ? ctx->bytes : 0; }
+int edv_last_launch_count(const edv_ctx *ctx) { return ctx ? ctx->launches : 0; }
+
+}  // extern "C"

@@ -1,0 +1,146 @@
+// LayerNorm and GroupNorm, fp32, HBM-bound row kernels.
+//   LayerNorm eps 1e-6: vision_transformer.py:97, block.py:69,85 (norm1/norm2), final norm :317
+//   LayerNorm eps 1e-5 + sinusoidal PE add: motion_module.py:155,161,164-172,197
+//   GroupNorm(32, eps 1e-6) on the motion-module input: motion_module.py:84,110
+// One wave per row; the row lives in registers (float4 per lane), mean and the centred second
+// moment are reduced with wavefront shuffles (two-pass in registers: no E[x^2]-E[x]^2 cancellation).
+#include "ops.hpp"
+
+namespace edv {
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+constexpr int LN_MAXV = 4;  // float4 per lane -> dim <= 1024
+
+__global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, RowMap in_map, const float *__restrict__ w,
+                                                         const float *__restrict__ b, float *__restrict__ y, RowMap out_map, long long rows,
+                                                         int dim, float eps, const float *__restrict__ pe, int rows_per_frame, int T) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + in_map(row) * dim;
+    const int nv = dim >> 2;
+    f32x4 v[LN_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            v[i] = *reinterpret_cast<const f32x4 *>(xr + 4 * c);
+            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        } else {
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    const float mean = wave_sum(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const f32x4 d = v[i] - mean;
+            q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)dim + eps);
+    float *yr = y + out_map(row) * dim;
+    const float *per = pe ? pe + (long long)((row / rows_per_frame) % T) * dim : nullptr;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const f32x4 g = *reinterpret_cast<const f32x4 *>(w + 4 * c);
+            const f32x4 be = *reinterpret_cast<const f32x4 *>(b + 4 * c);
+            f32x4 o = (v[i] - mean) * rstd * g + be;
+            if (per) o += *reinterpret_cast<const f32x4 *>(per + 4 * c);
+            *reinterpret_cast<f32x4 *>(yr + 4 * c) = o;
+        }
+    }
+}
+
+// GroupNorm statistics: one workgroup per (frame, group); x is channels-last [F, P, C].
+// Pass 1 mean, pass 2 centred second moment (the slab is re-read from L2).
+__global__ __launch_bounds__(256) void groupnorm_stats_kernel(const float *__restrict__ x, float *__restrict__ stats, int P, int C, int groups, float eps) {
+    __shared__ float red[4];
+    __shared__ float bc;
+    const int f = blockIdx.y, g = blockIdx.x, cg = C / groups;
+    const float *xf = x + (long long)f * P * C + g * cg;
+    const int n = P * cg;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int p = i / cg, c = i - p * cg;
+        s += xf[(long long)p * C + c];
+    }
+    s = wave_sum(s);
+    if (lane == 0) red[wv] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) bc = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+    __syncthreads();
+    const float mean = bc;
+    float q = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int p = i / cg, c = i - p * cg;
+        const float d = xf[(long long)p * C + c] - mean;
+        q += d * d;
+    }
+    q = wave_sum(q);
+    __syncthreads();
+    if (lane == 0) red[wv] = q;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float var = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+        stats[((long long)f * groups + g) * 2 + 0] = mean;
+        stats[((long long)f * groups + g) * 2 + 1] = rsqrtf(var + eps);
+    }
+}
+
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float *__restrict__ x, const float *__restrict__ stats, const float *__restrict__ w,
+                                                               const float *__restrict__ b, float *__restrict__ y, long long total4, int P, int C, int groups) {
+    const int cg = C / groups, c4n = C >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const long long pix = i / c4n;
+        const int c = (int)(i - pix * c4n) * 4;
+        const long long f = pix / P;
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(x + i * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ch = c + e, g = ch / cg;
+            const float mean = stats[(f * groups + g) * 2], rstd = stats[(f * groups + g) * 2 + 1];
+            o[e] = (v[e] - mean) * rstd * w[ch] + b[ch];
+        }
+        *reinterpret_cast<f32x4 *>(y + i * 4) = o;
+    }
+}
+
+}  // namespace
+
+int layernorm(const float *x, RowMap in_map, const float *w, const float *b, float *y, RowMap out_map, long long rows, int dim, float eps,
+              const float *pe, int rows_per_frame, int T, hipStream_t st) {
+    EDV_CHECK(x && w && b && y, "null operand");
+    EDV_CHECK(rows > 0, "empty problem");
+    EDV_CHECK(dim % 4 == 0 && dim <= 256 * LN_MAXV, "dim must be a multiple of 4 and <= 1024");
+    EDV_CHECK(!pe || (rows_per_frame > 0 && T > 0), "pe needs rows_per_frame and T");
+    const long long blocks = (rows + 3) / 4;
+    EDV_CHECK(blocks < (1ll << 31), "grid");
+    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, in_map, w, b, y, out_map, rows, dim, eps, pe,
+                       rows_per_frame > 0 ? rows_per_frame : 1, T > 0 ? T : 1);
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
+int groupnorm(const float *x, const float *w, const float *b, float *y, float *stats, int F, int P, int C, int groups, float eps, hipStream_t st) {
+    EDV_CHECK(x && w && b && y && stats, "null operand");
+    EDV_CHECK(F > 0 && P > 0 && C > 0 && groups > 0 && C % groups == 0 && C % 4 == 0, "shape");
+    EDV_CHECK(F <= 65535, "grid");
+    hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(groups, F), dim3(256), 0, st, x, stats, P, C, groups, eps);
+    EDV_LAUNCH_OK();
+    const long long total4 = (long long)F * P * C / 4;
+    const int blocks = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
+    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(blocks), dim3(256), 0, st, x, stats, w, b, y, total4, P, C, groups);
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
+}  // namespace edv

@@ -71,6 +71,8 @@ int bilinear(const float *x, float *y, int F, int H, int W, int C, int OH, int O
 int dot_channels(const float *x, const float *w, const float *b, float *y, long long M, int C, int act, hipStream_t st);
 int cls_rows(const float *cls, const float *pos, float *tokens, int F, int ntok, int D, hipStream_t st);
 int sigmoid_inplace(float *x, long long n, hipStream_t st);
+// planar bicubic image resize (cv2.INTER_CUBIC semantics) for infer_video_depth's pre-resize
+int resize_bicubic(const float *x, float *y, int NP, int H, int W, int OH, int OW, hipStream_t st);
 // pos-embed bicubic resample (vision_transformer.py:186-217): grid [S,S,D] -> [oh,ow,D]
 int bicubic_pos(const float *grid, float *out, int S, int D, int oh, int ow, float scale_h, float scale_w, hipStream_t st);
 

@@ -1,0 +1,501 @@
+"""Host-side mirror of the reference model class ``models.endodav.endodav``
+(reference ``models/endodav/endodav.py:53-254``), running the forward on MI355X through
+``libendodav_hip.so``.
+
+What this module owns (PyTorch = plumbing): the parameter tree with the reference's exact
+``state_dict`` key names and shapes, device placement, streams, output
+allocation.  What it does NOT own: arithmetic.  ``forward`` hands device pointers to
+``edv_forward``; there is no PyTorch/CPU fallback — on a CPU tensor, or with the shared library
+missing, it raises.
+
+Constructor arguments, attribute names reached by the reference's callers
+(``.pretrained.blocks[i].mlp.fc1``, ``.head.motion_modules``, ``.image_shape``) and error
+behaviour (``KeyError`` for an unknown encoder, ``AssertionError`` for ``num_frames <= 0``,
+``RuntimeError`` for T > num_frames, ``FileNotFoundError`` for a missing ``pretrained_path``)
+follow SURVEY.md §8b.  ``vitb`` is an extension.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+import os
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from .trainable import mark_only_part_as_trainable
+
+# infer settings of the reference (endodav.py:47-50)
+INFER_LEN = 32
+OVERLAP = 10
+KEYFRAMES = [6, 12, 24, 25, 26, 27, 28, 29, 30, 31]
+INTERP_LEN = 8
+
+# encoder -> (embed_dim, depth, heads, img_size of the stored pos_embed, tapped blocks)
+# vision_transformer.py:352-398 (vit_large keeps DinoVisionTransformer's img_size=224 default, hence
+# a 257-row pos_embed: SURVEY.md §7 "drop-in quirks"); taps endodav.py:76-79; vitb from
+# models/endodac/endodac.py:184-199.
+ENCODERS = {
+    "vits": (384, 12, 6, 518, (2, 5, 8, 11)),
+    "vitb": (768, 12, 12, 518, (2, 5, 8, 11)),
+    "vitl": (1024, 24, 16, 224, (4, 11, 17, 23)),
+}
+PATCH = 14
+
+
+# ---------------------------------------------------------------------------------------------
+# Parameter holders.  Same attribute names / shapes / default init as the reference modules.
+# None of them is ever *called* by the product path.
+# ---------------------------------------------------------------------------------------------
+class _Holder(nn.Module):
+    def forward(self, *a, **k):  # pragma: no cover - guard against accidental eager use
+        raise RuntimeError(f"{type(self).__name__} only holds parameters; the forward runs in libendodav_hip")
+
+
+class LoRALinear(nn.Linear):
+    """mylora/layers.py:90-157 (r > 0, merge_weights False): weight/bias + lora_A [r,in], lora_B [out,r]."""
+
+    def __init__(self, in_features, out_features, r=0, lora_alpha=1):
+        super().__init__(in_features, out_features)
+        self.r, self.lora_alpha = r, lora_alpha
+        self.scaling = lora_alpha / r
+        self.lora_A = nn.Parameter(self.weight.new_zeros((r, in_features)))
+        self.lora_B = nn.Parameter(self.weight.new_zeros((out_features, r)))
+        self.weight.requires_grad = False
+        nn.init.kaiming_uniform_(self.lora_A, a=math.sqrt(5))
+
+
+class DVLinear(LoRALinear):
+    """mylora/layers.py:328-393: adds lora_U [r,1] and lora_V [out,1]."""
+
+    def __init__(self, in_features, out_features, r=0, lora_alpha=1):
+        super().__init__(in_features, out_features, r, lora_alpha)
+        self.lora_U = nn.Parameter(self.weight.new_zeros(r, 1))
+        self.lora_V = nn.Parameter(self.weight.new_zeros(out_features, 1))
+        nn.init.kaiming_uniform_(self.lora_U, a=math.sqrt(5))
+        nn.init.kaiming_uniform_(self.lora_V, a=math.sqrt(5))
+
+
+class SSBLinear(nn.Linear):
+    """mylora/layers.py:396-430 (Linear_SSB): lora_A [in,1] and lora_B [out,1], initialised to one."""
+
+    def __init__(self, in_features, out_features, r=0):
+        super().__init__(in_features, out_features)
+        self.r = r
+        self.lora_A = nn.Parameter(torch.ones(in_features, 1))
+        self.lora_B = nn.Parameter(torch.ones(out_features, 1))
+        self.weight.requires_grad = False
+
+
+class DashLinear(LoRALinear):
+    """mylora/layers.py:487-585: LoRA + an 8-direction SVD term switched on after 100 calls."""
+
+    def __init__(self, in_features, out_features, r=0, lora_alpha=1):
+        super().__init__(in_features, out_features, r, lora_alpha)
+        self.index = 8
+        self.lora_index = nn.Parameter(self.weight.new_zeros(self.index))
+        self.weight_u_top = nn.Parameter(self.weight.new_zeros(out_features, self.index))
+        self.weight_vt_top = nn.Parameter(self.weight.new_zeros(self.index, in_features))
+        self.warmup = 100
+        self.FLAG = 0
+
+
+def _make_lora(kind: str, fin: int, fout: int, r: int) -> nn.Module:
+    if kind == "dvlora":
+        return DVLinear(fin, fout, r=r, lora_alpha=r)  # endodav.py:108-109
+    if kind == "lora":
+        return LoRALinear(fin, fout, r=r, lora_alpha=2 * r)  # endodav.py:111-112
+    if kind == "ssb":
+        return SSBLinear(fin, fout, r=r)  # endodav.py:114-115
+    if kind == "dash":
+        return DashLinear(fin, fout, r=r, lora_alpha=2 * r)  # endodav.py:117-118
+    raise ValueError(f"unknown lora_type {kind!r}")
+
+
+class _Gamma(_Holder):  # LayerScale, layer_scale.py:16-27
+    def __init__(self, dim, init_values=1e-5):
+        super().__init__()
+        self.gamma = nn.Parameter(init_values * torch.ones(dim))
+
+
+class _Attn(_Holder):  # layers/attention.py:36-54
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.num_heads = heads
+        self.qkv = nn.Linear(dim, dim * 3, bias=True)
+        self.proj = nn.Linear(dim, dim, bias=True)
+
+
+class _Mlp(_Holder):  # layers/mlp.py:16-31
+    def __init__(self, dim):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, 4 * dim)
+        self.fc2 = nn.Linear(4 * dim, dim)
+
+
+class _Block(_Holder):  # layers/block.py:42-109
+    def __init__(self, dim, heads):
+        super().__init__()
+        self.norm1 = nn.LayerNorm(dim, eps=1e-6)
+        self.attn = _Attn(dim, heads)
+        self.ls1 = _Gamma(dim)
+        self.norm2 = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = _Mlp(dim)
+        self.ls2 = _Gamma(dim)
+
+
+class _PatchEmbed(_Holder):  # layers/patch_embed.py:38-66
+    def __init__(self, dim):
+        super().__init__()
+        self.proj = nn.Conv2d(3, dim, kernel_size=PATCH, stride=PATCH)
+
+
+class _Backbone(_Holder):
+    """Parameter tree of DinoVisionTransformer (vision_transformer.py:43-184)."""
+
+    def __init__(self, dim, depth, heads, img_size):
+        super().__init__()
+        self.embed_dim = self.num_features = dim
+        self.n_blocks, self.num_heads, self.patch_size = depth, heads, PATCH
+        n_patches = (img_size // PATCH) ** 2
+        self.patch_embed = _PatchEmbed(dim)
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
+        self.pos_embed = nn.Parameter(torch.zeros(1, n_patches + 1, dim))
+        self.blocks = nn.ModuleList([_Block(dim, heads) for _ in range(depth)])
+        self.norm = nn.LayerNorm(dim, eps=1e-6)
+        self.mask_token = nn.Parameter(torch.zeros(1, dim))
+        nn.init.trunc_normal_(self.pos_embed, std=0.02)  # vision_transformer.py:180-184
+        nn.init.normal_(self.cls_token, std=1e-6)
+        for m in self.modules():
+            if isinstance(m, nn.Linear):  # init_weights_vit_timm, :342-348
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+
+class _PosEnc(_Holder):  # motion_module.py:180-198
+    def __init__(self, d_model, max_len):
+        super().__init__()
+        position = torch.arange(max_len).unsqueeze(1)
+        div_term = torch.exp(torch.arange(0, d_model, 2) * (-math.log(10000.0) / d_model))
+        pe = torch.zeros(1, max_len, d_model)
+        pe[0, :, 0::2] = torch.sin(position * div_term)
+        pe[0, :, 1::2] = torch.cos(position * div_term)
+        self.register_buffer("pe", pe)
+
+
+class _TemporalAttention(_Holder):  # motion_module.py:200-228 + attention.py:44-91
+    def __init__(self, dim, max_len):
+        super().__init__()
+        self.to_q = nn.Linear(dim, dim, bias=False)
+        self.to_k = nn.Linear(dim, dim, bias=False)
+        self.to_v = nn.Linear(dim, dim, bias=False)
+        self.to_out = nn.ModuleList([nn.Linear(dim, dim), nn.Dropout(0.0)])
+        self.pos_encoder = _PosEnc(dim, max_len)
+
+
+class _GEGLU(_Holder):  # attention.py:363-384
+    def __init__(self, dim, inner):
+        super().__init__()
+        self.proj = nn.Linear(dim, inner * 2)
+
+
+class _FeedForward(_Holder):  # attention.py:296-338
+    def __init__(self, dim):
+        super().__init__()
+        self.net = nn.ModuleList([_GEGLU(dim, dim * 4), nn.Dropout(0.0), nn.Linear(dim * 4, dim)])
+
+
+class _TemporalBlock(_Holder):  # motion_module.py:129-177
+    def __init__(self, dim, max_len):
+        super().__init__()
+        self.attention_blocks = nn.ModuleList([_TemporalAttention(dim, max_len) for _ in range(2)])
+        self.norms = nn.ModuleList([nn.LayerNorm(dim) for _ in range(2)])
+        self.ff = _FeedForward(dim)
+        self.ff_norm = nn.LayerNorm(dim)
+
+
+class _TemporalTransformer(_Holder):  # motion_module.py:68-126
+    def __init__(self, channels, max_len):
+        super().__init__()
+        self.norm = nn.GroupNorm(num_groups=32, num_channels=channels, eps=1e-6, affine=True)
+        self.proj_in = nn.Linear(channels, channels)
+        self.transformer_blocks = nn.ModuleList([_TemporalBlock(channels, max_len)])
+        self.proj_out = nn.Linear(channels, channels)
+
+
+class TemporalModule(_Holder):  # motion_module.py:32-65, zero_initialize=True
+    def __init__(self, in_channels, max_len):
+        super().__init__()
+        self.temporal_transformer = _TemporalTransformer(in_channels, max_len)
+        for p in self.temporal_transformer.proj_out.parameters():
+            p.detach().zero_()
+
+
+class _RCU(_Holder):  # util/blocks.py:37-66
+    def __init__(self, f):
+        super().__init__()
+        self.conv1 = nn.Conv2d(f, f, 3, 1, 1, bias=True)
+        self.conv2 = nn.Conv2d(f, f, 3, 1, 1, bias=True)
+
+
+class _Fusion(_Holder):  # util/blocks.py:94-133
+    def __init__(self, f):
+        super().__init__()
+        self.out_conv = nn.Conv2d(f, f, 1, 1, 0, bias=True)
+        self.resConfUnit1 = _RCU(f)
+        self.resConfUnit2 = _RCU(f)
+
+
+class _Interp(nn.Module):  # endodav/layers.py:194-204; no parameters, keeps Sequential indices 0,2,4
+    pass
+
+
+class HeadDepth(_Holder):  # endodav/layers.py:206-221
+    def __init__(self, f):
+        super().__init__()
+        self.head = nn.Sequential(nn.Conv2d(f, f // 2, 3, 1, 1), _Interp(), nn.Conv2d(f // 2, 32, 3, 1, 1), nn.ReLU(), nn.Conv2d(32, 1, 1, 1, 0))
+
+
+class _Head(_Holder):
+    """Parameter tree of DPTHeadPyramid (dpt.py:47-124, dpt_temporal.py:22-51, dpt_pyramid.py:22-49)."""
+
+    def __init__(self, in_channels, features, out_channels, num_frames, disable_conv_head):
+        super().__init__()
+        oc = list(out_channels)
+        self.projects = nn.ModuleList([nn.Conv2d(in_channels, c, 1, 1, 0) for c in oc])
+        self.resize_layers = nn.ModuleList([
+            nn.ConvTranspose2d(oc[0], oc[0], 4, 4, 0),
+            nn.ConvTranspose2d(oc[1], oc[1], 2, 2, 0),
+            nn.Identity(),
+            nn.Conv2d(oc[3], oc[3], 3, 2, 1),
+        ])
+        s = nn.Module()
+        for j in range(4):
+            setattr(s, f"layer{j + 1}_rn", nn.Conv2d(oc[j], features, 3, 1, 1, bias=False))
+        s.stem_transpose = None
+        for j in (1, 2, 3, 4):
+            setattr(s, f"refinenet{j}", _Fusion(features))
+        if disable_conv_head:
+            s.output_conv1 = nn.Conv2d(features, features // 2, 3, 1, 1)
+            s.output_conv2 = nn.Sequential(nn.Conv2d(features // 2, 32, 3, 1, 1), nn.ReLU(True), nn.Conv2d(32, 1, 1, 1, 0), nn.ReLU(True), nn.Identity())
+        self.scratch = s
+        assert num_frames > 0  # dpt_temporal.py:34
+        self.motion_modules = nn.ModuleList([
+            TemporalModule(oc[2], num_frames), TemporalModule(oc[3], num_frames),
+            TemporalModule(features, num_frames), TemporalModule(features, num_frames),
+        ])
+        self.disable_conv_head = disable_conv_head
+        if not disable_conv_head:
+            for k in (1, 2, 3, 4):
+                setattr(self, f"conv_depth_{k}", HeadDepth(features))
+
+
+class _NativeCtx:
+    """Owns one ``edv_ctx`` (one device).  Destroyed with the last module/replica that references it."""
+
+    def __init__(self, handle: int, device: torch.device):
+        self.handle, self.device, self.sig = handle, device, None
+
+    def __del__(self):
+        try:
+            _lib.load().edv_destroy(C.c_void_p(self.handle))
+        except Exception:
+            pass
+
+
+# ---------------------------------------------------------------------------------------------
+class endodav(nn.Module):
+    """Drop-in for ``models.endodav.endodav`` (constructor: endodav.py:53-73)."""
+
+    def __init__(
+        self,
+        encoder="vitl",
+        features=256,
+        out_channels=[256, 512, 1024, 1024],
+        use_bn=False,
+        use_clstoken=False,
+        num_frames=32,
+        pe="ape",
+        r=4,
+        image_shape=(224, 280),
+        lora_type="lora",
+        pretrained_path=None,
+        residual_block_indexes=[],
+        include_cls_token=True,
+        inv_sigmoid=False,
+        temporal_lora=False,
+        disable_conv_head=False,
+        out_sigmoid=False,
+    ):
+        super().__init__()
+        dim, depth, heads, img_size, taps = ENCODERS[encoder]  # KeyError for an unknown encoder, like endodav.py:92
+        if use_bn:
+            raise NotImplementedError("use_bn=True (BatchNorm in the fusion blocks) is not built; no reference caller sets it")
+        if use_clstoken:
+            raise NotImplementedError("use_clstoken=True (readout projections) is not built; no reference caller sets it")
+        if pe != "ape":
+            raise NotImplementedError("only pe='ape' (the reference default) is built")
+        if list(residual_block_indexes):
+            raise NotImplementedError("residual_block_indexes != [] is not built yet (every endodav script passes --disable_residual_block)")
+        self.encoder = encoder
+        self.intermediate_layer_idx = {encoder: list(taps)}
+        self.image_shape = tuple(image_shape)
+        self.r = r
+        self.lora_type = lora_type
+        self.num_frames = num_frames
+        self.include_cls_token = include_cls_token
+        self.inv_sigmoid, self.out_sigmoid = inv_sigmoid, out_sigmoid
+        self.temporal_lora, self.disable_conv_head = temporal_lora, disable_conv_head
+        self.features, self.out_channels = features, list(out_channels)
+
+        self.pretrained = _Backbone(dim, depth, heads, img_size)
+        self.head = _Head(dim, features, out_channels, num_frames, disable_conv_head)
+
+        if lora_type != "none":  # endodav.py:102-137
+            for blk in self.pretrained.blocks:
+                blk.mlp.fc1 = _make_lora(lora_type, dim, 4 * dim, r)
+                blk.mlp.fc2 = _make_lora(lora_type, 4 * dim, dim, r)
+            if temporal_lora:
+                for tm in self.head.motion_modules:
+                    for blk in tm.temporal_transformer.transformer_blocks:
+                        old = blk.ff.net[2]
+                        blk.ff.net[2] = _make_lora(lora_type, old.in_features, old.out_features, r)
+
+        if pretrained_path is not None:  # endodav.py:139-144
+            print("load pretrained weight from {}\n".format(pretrained_path))
+            path = os.path.join(pretrained_path, "video_depth_anything_{}.pth".format(self.encoder))
+            self.load_state_dict(torch.load(path, map_location="cpu", weights_only=True), strict=False)
+
+        mark_only_part_as_trainable(self.pretrained)  # endodav.py:146-148
+        mark_only_part_as_trainable(self.head)
+        mark_only_part_as_trainable(self.head.motion_modules, is_trainable=False)
+
+        # ---- native contexts, one per device, created lazily.  The dict is shared (by reference) with
+        # nn.DataParallel replicas, each of which then finds or creates the context of its own device.
+        self._native: Dict[str, "_NativeCtx"] = {}
+        self._capture = False
+
+    # -------------------------------------------------------------------------------------
+    def _config(self) -> _lib.EdvConfig:
+        dim, depth, heads, _, taps = ENCODERS[self.encoder]
+        cfg = _lib.EdvConfig()
+        cfg.abi_version = _lib.ABI_VERSION
+        cfg.embed_dim, cfg.depth, cfg.num_heads = dim, depth, heads
+        cfg.taps = (C.c_int32 * 4)(*taps)
+        cfg.features = self.features
+        cfg.out_channels = (C.c_int32 * 4)(*self.out_channels)
+        cfg.image_h, cfg.image_w = int(self.image_shape[0]), int(self.image_shape[1])
+        cfg.num_frames = self.num_frames
+        cfg.pos_tokens = int(self.pretrained.pos_embed.shape[1])
+        cfg.lora_type = _lib.LORA_TYPES[self.lora_type]
+        cfg.lora_rank = self.r
+        cfg.include_cls_token = int(bool(self.include_cls_token))
+        cfg.conv_head = int(not self.disable_conv_head)
+        cfg.inv_sigmoid, cfg.out_sigmoid = int(bool(self.inv_sigmoid)), int(bool(self.out_sigmoid))
+        cfg.temporal_lora = int(bool(self.temporal_lora))
+        cfg.dash_active = 0
+        return cfg
+
+    def _ensure_ctx(self, device: torch.device) -> int:
+        lib = _lib.load()
+        key = str(device)
+        nat = self._native.get(key)
+        if nat is None:
+            h = C.c_void_p()
+            cfg = self._config()
+            _lib.check(lib.edv_create(C.byref(cfg), C.byref(h)), "edv_create")
+            nat = self._native[key] = _NativeCtx(h.value, device)
+        lib.edv_set_capture(C.c_void_p(nat.handle), int(self._capture))
+        self._last = nat
+        # (re)bind + repack whenever a tensor moved or was written (optimizer step, load_state_dict)
+        sd = self.state_dict(keep_vars=True)
+        sig = tuple((k, v.data_ptr(), v._version) for k, v in sd.items())
+        if sig != nat.sig:
+            for k, v in sd.items():
+                if not v.is_floating_point():
+                    continue
+                if v.device != device or v.dtype != torch.float32 or not v.is_contiguous():
+                    raise RuntimeError(f"parameter {k} must be a contiguous float32 tensor on {device} (got {v.dtype} on {v.device})")
+                shape = (C.c_int64 * v.dim())(*v.shape)
+                _lib.check(lib.edv_bind_param(C.c_void_p(nat.handle), k.encode(), v.data_ptr(), shape, v.dim()), f"edv_bind_param({k})")
+            _lib.check(lib.edv_prepare(C.c_void_p(nat.handle), C.c_void_p(_lib.stream_ptr(device))), "edv_prepare")
+            nat.sig = sig
+        return nat.handle
+
+    def output_shapes(self) -> List[Tuple[int, int]]:
+        ph, pw = self.image_shape[0] // PATCH, self.image_shape[1] // PATCH
+        if self.disable_conv_head:
+            h, w = self.image_shape
+            out = []
+            for _ in range(4):
+                out.append((h, w))
+                h, w = h // 2, w // 2
+            return out
+        return [(ph * m, pw * m) for m in (16, 8, 4, 2)]
+
+    # -------------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor) -> Dict[Tuple[str, int], torch.Tensor]:
+        """``x``: [B, T, 3, H, W] float32 in [0, 1] on a ROCm device → {("disp", s): [B*T, 1, h_s, w_s]}."""
+        if x.dim() != 5 or x.shape[2] != 3:
+            raise ValueError(f"expected a clip [B, T, 3, H, W], got {tuple(x.shape)}")
+        if not x.is_cuda:
+            raise RuntimeError("endodav_amd runs on MI355X only: the clip must be a CUDA/ROCm tensor (there is no CPU fallback)")
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError(
+                "backward through libendodav_hip is not built yet (SURVEY.md §8f rank 3): call under torch.no_grad()"
+            )
+        B, T, _, H, W = x.shape
+        assert self.image_shape[0] % PATCH == 0, f"Input image height {self.image_shape[0]} is not a multiple of patch height {PATCH}"
+        assert self.image_shape[1] % PATCH == 0, f"Input image width {self.image_shape[1]} is not a multiple of patch width: {PATCH}"
+        if T > self.num_frames:  # motion_module.py:197: pe[:, :T] cannot broadcast
+            raise RuntimeError(f"The size of tensor a ({T}) must match the size of tensor b ({self.num_frames}) at non-singleton dimension 1")
+        x = x.detach().contiguous().float()
+        with torch.cuda.device(x.device):
+            ctx = self._ensure_ctx(x.device)
+            outs = [torch.empty((B * T, 1, h, w), device=x.device, dtype=torch.float32) for (h, w) in self.output_shapes()]
+            ptrs = (C.c_void_p * 4)(*[o.data_ptr() for o in outs])
+            _lib.check(
+                _lib.load().edv_forward(C.c_void_p(ctx), x.data_ptr(), B, T, H, W, ptrs, C.c_void_p(_lib.stream_ptr(x.device))),
+                "edv_forward",
+            )
+        return {("disp", s): outs[s] for s in range(4)}
+
+    # ---- debug taps for the per-stage parity tests --------------------------------------------
+    def set_capture(self, on: bool) -> None:
+        self._capture = bool(on)
+
+    def stage(self, name: str) -> torch.Tensor:
+        """Flat copy of an internal stage of the last forward (see ``edv_stage_copy``)."""
+        lib = _lib.load()
+        nat = self._last
+        n = C.c_size_t()
+        _lib.check(lib.edv_stage_copy(C.c_void_p(nat.handle), name.encode(), None, C.byref(n), None), "edv_stage_copy")
+        out = torch.empty(n.value, device=nat.device, dtype=torch.float32)
+        with torch.cuda.device(nat.device):
+            _lib.check(lib.edv_stage_copy(C.c_void_p(nat.handle), name.encode(), out.data_ptr(), C.byref(n), C.c_void_p(_lib.stream_ptr(nat.device))), "edv_stage_copy")
+        return out
+
+    def launch_count(self) -> int:
+        nat = getattr(self, "_last", None)
+        return int(_lib.load().edv_last_launch_count(C.c_void_p(nat.handle))) if nat else 0
+
+    def device_bytes(self) -> int:
+        nat = getattr(self, "_last", None)
+        return int(_lib.load().edv_device_bytes(C.c_void_p(nat.handle))) if nat else 0
+
+    # -------------------------------------------------------------------------------------
+    def infer_video_depth(self, frames, input_size=518, device="cuda"):
+        """Sliding-window inference over a whole video (endodav.py:162-254).
+
+        ``frames``: uint8 [N, H, W, 3].  Returns float32 [N, H, W].  Windows of 32 frames, step 22; the
+        first 10 slots of every later window are refilled with key frames of the previous window's
+        INPUT; windows are stitched by a least-squares scale/shift on the overlap and a linear
+        cross-fade over 8 frames.
+        """
+        from .video import infer_video_depth as _impl
+
+        return _impl(self, frames, input_size=input_size, device=device)

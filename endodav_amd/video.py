@@ -1,0 +1,132 @@
+"""Whole-video inference around the per-clip forward: windowing, key-frame reuse and stitching
+(reference ``models/endodav/endodav.py:162-254`` with ``utils/util.py:16-74`` and the
+``Resize`` size rule of ``models/endodav/util/transform.py:52-105``).
+
+Differences in *where* work happens, not in what is computed:
+  - frames are uploaded once, converted to float and (if needed) bicubically resized on the GPU
+    by ``edv_resize_bicubic`` instead of per-frame ``cv2.resize`` on the host;
+  - each window's 32 disparity maps are resized to the native frame size on the GPU by
+    ``edv_bilinear`` and come back in ONE device→host copy instead of 32;
+  - the least-squares scale/shift and the cross-fade run in numpy float32 exactly as the reference's.
+
+The cv2.INTER_CUBIC pre-resize is "parity unpinned" (cv2 is absent from the build
+container and the reference has no fixture for it); the kernel implements the published algorithm
+(Keys cubic, a = -0.75, half-pixel centres, clamped borders).  When the frames already have the
+network's size the resize is the identity and the whole path is pinned by ``tests/test_video.py``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+
+INFER_LEN = 32
+OVERLAP = 10
+KEYFRAMES = [6, 12, 24, 25, 26, 27, 28, 29, 30, 31]
+INTERP_LEN = 8
+
+
+# ---------------------------------------------------------------------------------------------
+# host logic (pure numpy / python; shared with the tests)
+# ---------------------------------------------------------------------------------------------
+def lower_bound_size(width: int, height: int, target_w: int, target_h: int, multiple: int = 14) -> Tuple[int, int]:
+    """transform.py:52-105 for keep_aspect_ratio=True, resize_method='lower_bound':
+    scale both axes by the larger of the two ratios, round to a multiple of 14, never below target."""
+    scale = max(target_w / width, target_h / height)
+
+    def snap(x, lo):
+        y = int(np.round(x / multiple) * multiple)
+        if y < lo:
+            y = int(np.ceil(x / multiple) * multiple)
+        return y
+
+    return snap(scale * width, target_w), snap(scale * height, target_h)
+
+
+def window_plan(n_frames: int) -> Tuple[int, List[int]]:
+    """endodav.py:185-193: pad with copies of the last frame to k*22+10 frames; windows start every 22."""
+    step = INFER_LEN - OVERLAP
+    pad = (step - (n_frames % step)) % step + (INFER_LEN - step)
+    return n_frames + pad, list(range(0, n_frames, step))
+
+
+def scale_and_shift(pred: np.ndarray, target: np.ndarray) -> Tuple[float, float]:
+    """Least-squares (s, t) with s*pred + t ≈ target over all pixels (utils/util.py:40-63, mask = 1)."""
+    pred = pred.astype(np.float32)
+    target = target.astype(np.float32)
+    a00 = np.sum(pred * pred)
+    a01 = np.sum(pred)
+    a11 = np.float32(pred.size)
+    b0 = np.sum(pred * target)
+    b1 = np.sum(target)
+    det = a00 * a11 - a01 * a01
+    if det == 0:
+        return 1, 0
+    return (a11 * b0 - a01 * b1) / det, (-a01 * b0 + a00 * b1) / det
+
+
+def stitch_windows(depths: List[np.ndarray], n_keep: int) -> np.ndarray:
+    """endodav.py:213-254.  ``depths``: per-window arrays [32, H, W] in window order."""
+    align_len = OVERLAP - INTERP_LEN
+    out: List[np.ndarray] = []
+    # cross-fade weights of get_interpolate_frames (utils/util.py:66-74): python floats 0, 1/7, ..., 1
+    step = 1.0 / (INTERP_LEN - 1)
+    fade = [0.0] + [i * step for i in range(1, INTERP_LEN - 1)] + [1.0]
+    for wi, cur in enumerate(depths):
+        if wi == 0:
+            out.extend(cur[i] for i in range(INFER_LEN))
+            continue
+        pre = out[-INTERP_LEN:]
+        post = [cur[i] for i in range(align_len, OVERLAP)]
+        s, t = scale_and_shift(np.concatenate(post), np.concatenate(pre))
+        for i in range(INTERP_LEN):
+            p = post[i] * s + t
+            p[p < 0] = 0
+            out[len(out) - INTERP_LEN + i] = pre[i] * (1 - fade[i]) + p * fade[i]
+        for i in range(OVERLAP, INFER_LEN):
+            d = cur[i] * s + t
+            d[d < 0] = 0
+            out.append(d)
+    return np.stack(out[:n_keep], axis=0)
+
+
+# ---------------------------------------------------------------------------------------------
+def infer_video_depth(model, frames, input_size=518, device="cuda"):
+    lib = _lib.load()
+    frames = np.asarray(frames)
+    if frames.ndim != 4 or frames.shape[-1] != 3:
+        raise ValueError(f"expected frames [N, H, W, 3], got {frames.shape}")
+    n, fh, fw = frames.shape[:3]
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("infer_video_depth runs on MI355X only (device must be a CUDA/ROCm device)")
+    ih, iw = model.image_shape
+    tw, th = lower_bound_size(fw, fh, iw, ih)
+    total, starts = window_plan(n)
+
+    with torch.cuda.device(dev), torch.no_grad():
+        st = C.c_void_p(_lib.stream_ptr(dev))
+        vid = torch.from_numpy(np.ascontiguousarray(frames)).to(dev)
+        vid = vid.permute(0, 3, 1, 2).contiguous().to(torch.float32).div_(255.0)  # [N,3,H,W] in [0,1]
+        if (th, tw) != (fh, fw):
+            small = torch.empty((n, 3, th, tw), device=dev, dtype=torch.float32)
+            _lib.check(lib.edv_resize_bicubic(vid.data_ptr(), small.data_ptr(), n * 3, fh, fw, th, tw, st), "edv_resize_bicubic")
+            vid = small
+        index = torch.arange(total, device=dev).clamp_(max=n - 1)  # padding = copies of the last frame
+
+        windows: List[np.ndarray] = []
+        pre = None
+        for s0 in starts:
+            cur = vid[index[s0:s0 + INFER_LEN]].unsqueeze(0).contiguous()  # [1,32,3,th,tw]
+            if pre is not None:
+                cur[:, :OVERLAP] = pre[:, KEYFRAMES]
+            disp = model(cur)[("disp", 0)]  # [32,1,ih,iw]
+            full = torch.empty((INFER_LEN, fh, fw), device=dev, dtype=torch.float32)
+            _lib.check(lib.edv_bilinear(disp.data_ptr(), full.data_ptr(), INFER_LEN, disp.shape[-2], disp.shape[-1], 1, fh, fw, st), "edv_bilinear")
+            windows.append(full.cpu().numpy())
+            pre = cur
+    return stitch_windows(windows, n)

@@ -88,6 +88,8 @@ int edv_output_shape(const edv_ctx *ctx, int32_t scale, int32_t *h, int32_t *w);
  * tests.  name in {"tokens","block0","tap0".."tap3","mm0","mm1","path4".."path1"}; head
  * stages are channels-last [frames,h,w,C].  Returns element count through *n (dst may be NULL). */
 int edv_stage_copy(edv_ctx *ctx, const char *name, float *dst_dev, size_t *n, void *stream);
+/* Debug: when on, edv_forward also snapshots the in-place residual stream ("tokens", "block0"). */
+int edv_set_capture(edv_ctx *ctx, int on);
 /* Bytes of device memory the context currently holds (packed weights + workspace). */
 size_t edv_device_bytes(const edv_ctx *ctx);
 /* Seconds spent in the dominant kernels are measured by the caller with HIP events; this
@@ -143,6 +145,23 @@ int edv_dot_channels(const float *x_dev, const float *w_dev, const float *b_dev,
  * x [F,3,H,W] to [ih,iw], ImageNet normalisation, and im2col into rows
  * [F*(ih/14)*(iw/14), 588] ordered (c, ky, kx) like the Conv2d weight. */
 int edv_patchify(const float *x_dev, float *cols_dev, int32_t F, int32_t H, int32_t W, int32_t ih, int32_t iw, void *stream);
+
+/* ConvTranspose2d with kernel == stride == s (dpt.py:71-82), channels-last x [F,h,w,C] -> y [F,h*s,w*s,C];
+ * w [C,C,s,s] and b [C] in torch layout; wpack [s*s*C*C] and bpack [s*s*C] are caller scratch. */
+int edv_conv_transpose(const float *x_dev, const float *w_dev, const float *b_dev, float *wpack_dev, float *bpack_dev, float *y_dev, int32_t F, int32_t h,
+              int32_t w, int32_t C, int32_t s, void *stream);
+
+/* interpolate_pos_encoding's bicubic resample (vision_transformer.py:186-217): grid [S,S,D] -> out [oh,ow,D]
+ * with scale factors (oh+0.1)/S, (ow+0.1)/S exactly as F.interpolate(scale_factor=...) receives them. */
+int edv_bicubic_pos(const float *grid_dev, float *out_dev, int32_t S, int32_t D, int32_t oh, int32_t ow, double scale_h, double scale_w, void *stream);
+
+/* Bicubic resize of `planes` images [H,W] -> [OH,OW] (Keys cubic a=-0.75, half-pixel centres, clamped
+ * borders = cv2.INTER_CUBIC): the frame pre-resize of infer_video_depth (endodav.py:170-181,196). */
+int edv_resize_bicubic(const float *x_dev, float *y_dev, int32_t planes, int32_t H, int32_t W, int32_t OH, int32_t OW, void *stream);
+
+/* out = W + scale * (B∘V)(A∘U)  (U, V may be NULL): the LoRA / DV-LoRA fold of mylora/layers.py:148-157,384-393. */
+int edv_fold_lora(const float *W_dev, const float *A_dev, const float *B_dev, const float *U_dev, const float *V_dev, float scale, float *out_dev,
+                  int32_t nout, int32_t nin, int32_t r, void *stream);
 
 #ifdef __cplusplus
 }

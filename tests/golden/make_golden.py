@@ -63,6 +63,12 @@ def _install_standins() -> None:
 
     cv2 = types.ModuleType("cv2")
     cv2.INTER_CUBIC, cv2.INTER_AREA, cv2.INTER_NEAREST = 2, 3, 0
+
+    def resize(img, size, interpolation=None):  # only the identity case is exercised (video golden)
+        assert (img.shape[1], img.shape[0]) == tuple(size), "stand-in cv2.resize: identity only"
+        return img
+
+    cv2.resize = resize
     sys.modules["cv2"] = cv2
 
     ed = types.ModuleType("easydict")
@@ -103,13 +109,80 @@ def strided(a: np.ndarray, step: int = 7) -> np.ndarray:
     return np.ascontiguousarray(a[..., ::step, ::step])
 
 
+VIDEO_CASE = dict(n_frames=40, h=28, w=42)
+
+
+def fake_window_disp(call: int, h: int, w: int):
+    """Synthetic per-window disparity [32,1,h,w]: a shared smooth field, window-specific gain/offset and noise,
+    so that the least-squares alignment between windows has real work to do."""
+    from endodav_amd import synth
+
+    base = synth.uniform("video:base", (32, 1, h, w), 0.5, 2.0)
+    noise = synth.uniform(f"video:noise:{call}", (32, 1, h, w), -0.05, 0.05)
+    return ((1.0 + 0.3 * call) * base + 0.2 * call + noise).astype(np.float32)
+
+
+def make_video_golden(ref):
+    """Pins windowing, key-frame reuse and stitching of infer_video_depth (reference endodav.py:162-254):
+    the reference method runs on CPU with its forward replaced by a recorder that returns synthetic maps."""
+    from endodav_amd import synth
+
+    n, h, w = VIDEO_CASE["n_frames"], VIDEO_CASE["h"], VIDEO_CASE["w"]
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        model = ref.endodav(encoder="vits", features=32, out_channels=[32, 32, 64, 64], image_shape=(h, w), lora_type="none",
+                            disable_conv_head=True, pretrained_path=None).eval()
+    frames = (synth.uniform("video:frames", (n, h, w, 3), 0.0, 1.0) * 255).astype(np.uint8)
+    seen = []
+
+    def recorder(x):
+        seen.append(x[0].mean(dim=(1, 2, 3)).numpy().astype(np.float64))  # per-frame mean of the window input
+        return {("disp", 0): torch.from_numpy(fake_window_disp(len(seen) - 1, h, w))}
+
+    model.forward = recorder
+    out = model.infer_video_depth(frames, device="cpu")
+    assert out.shape == (n, h, w)
+    path = os.path.join(HERE, "video_stitch.npz")
+    np.savez_compressed(path, out=out.astype(np.float32), window_input_means=np.stack(seen))
+    print(f"video_stitch: {len(seen)} windows, out mean {out.mean():.4f}; wrote {os.path.getsize(path)} B")
+
+
+def dump_state_keys(ref):
+    """state_dict key -> shape listings of the reference for the drop-in check."""
+    import json
+
+    combos = {
+        "vits_dvlora_vda": dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384], lora_type="dvlora", disable_conv_head=True),
+        "vits_lora_conv": dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384], lora_type="lora"),
+        "vits_ssb_vda_tlora": dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384], lora_type="ssb", disable_conv_head=True, temporal_lora=True),
+        "vits_dash_conv": dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384], lora_type="dash"),
+        "vits_none_vda": dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384], lora_type="none", disable_conv_head=True),
+        "vitl_dvlora_vda": dict(encoder="vitl", features=256, out_channels=[256, 512, 1024, 1024], lora_type="dvlora", disable_conv_head=True),
+    }
+    out = {}
+    for name, kw in combos.items():
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            m = ref.endodav(**kw, pretrained_path=None)
+        out[name] = {"kwargs": kw, "keys": [[k, list(v.shape)] for k, v in m.state_dict().items()],
+                     "trainable": sorted(n for n, p in m.named_parameters() if p.requires_grad)}
+    path = os.path.join(HERE, "state_keys.json")
+    with open(path, "w") as f:
+        json.dump(out, f)
+    print(f"state_keys: {len(out)} configurations; wrote {os.path.getsize(path)} B")
+
+
 def main(argv):
     from endodav_amd import synth
     from oracle import endodav_oracle as orc
     from tests.golden.cases import CASES, STAGE_KEYS
 
     ref = load_reference()
-    names = argv or list(CASES)
+    if not argv or "video" in argv:
+        make_video_golden(ref)
+    if not argv or "keys" in argv:
+        dump_state_keys(ref)
+    names = [a for a in argv if a not in ("video", "keys")] if argv else list(CASES)
     torch.set_num_threads(8)
     for name in names:
         kwargs, (B, T, H, W), kind, store = CASES[name]

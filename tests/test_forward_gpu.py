@@ -1,0 +1,160 @@
+"""End-to-end parity of the HIP forward (through the C ABI, via the host module) on MI355X.
+
+Two independent checks per case:
+  (1) against the GOLDEN fixtures captured from the imported reference (tests/golden/*.npz);
+  (2) against the oracle run on this box's CPU on the same seeded weights and clip, stage by
+      stage, so that a failure names the first stage that diverges.
+Gates (BASELINE.md asks for depth within 1e-3 relative of the reference):
+  G1  every pixel, every scale: |disp - disp_ref| <= 5e-5 * max|disp_ref|   (measured 1e-6 .. 9e-6)
+  G2  every pixel: abs_rel(depth, depth_ref) <= 1e-4                        (BASELINE's quality metric; measured ~1e-6 .. 1e-5)
+  G3  per-pixel depth relative error <= 1e-3 wherever disp_ref >= 1 % of the frame maximum (see
+      helpers.depth_gate for why the ReLU zero-crossing pixels cannot be held per-pixel by ANY fp32
+      implementation), and on ALL pixels for the full-size BASELINE geometries.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import endodav_oracle as orc
+from tests import helpers as H
+from tests.golden.cases import CASES
+
+pytestmark = pytest.mark.gpu
+
+DEPTH_RTOL = 1e-3   # BASELINE gate (G3)
+DISP_RTOL = 5e-5    # G1: max|Δdisp| / max|disp|
+ABS_REL_MAX = 1e-4  # G2
+
+MICRO = [n for n in CASES if n.startswith("micro_")]
+
+
+def run_hip(name, cuda, capture=False):
+    model, kwargs, shape, kind, store = H.build_model(name)
+    model = model.to(cuda)
+    model.set_capture(capture)
+    x = H.case_input(name).to(cuda)
+    with torch.no_grad():
+        out = model(x)
+    torch.cuda.synchronize()
+    return model, kwargs, x, out
+
+
+def check_against_golden(name, out, store, all_pixels=False):
+    g = H.load_golden(name)
+    for s in range(4):
+        a = out[("disp", s)].cpu().numpy()
+        ref_stats = g[f"disp{s}_stats"]
+        got_stats = H.frame_stats(a)
+        scale = np.abs(ref_stats[:, 2]).max()
+        assert np.abs(got_stats[:, :3] - ref_stats[:, :3]).max() <= DISP_RTOL * max(scale, 1e-6), f"{name} disp{s} per-frame stats"
+        assert np.abs(got_stats[:, 3] - ref_stats[:, 3]).max() <= DISP_RTOL * np.abs(ref_stats[:, 3]).max(), f"{name} disp{s} l2"
+        ref = g[f"disp{s}"]
+        cmp = a if store == "full" else a[..., ::7, ::7]
+        assert cmp.shape == ref.shape, (cmp.shape, ref.shape)
+        e = H.rel_err(cmp, ref)
+        assert e <= DISP_RTOL, f"{name} disp{s}: scale-relative error {e:.3e}"
+        ar = H.abs_rel(cmp, ref)
+        assert ar <= ABS_REL_MAX, f"{name} disp{s}: abs_rel {ar:.3e}"
+        de, excl = H.depth_gate(cmp, ref)
+        assert de <= DEPTH_RTOL, f"{name} disp{s}: depth relative error {de:.3e} ({excl:.1%} of pixels below the floor)"
+        if all_pixels:
+            naive = H.depth_rel_err(cmp, ref)
+            assert naive <= DEPTH_RTOL, f"{name} disp{s}: all-pixel depth relative error {naive:.3e}"
+
+
+@pytest.mark.parametrize("name", MICRO)
+def test_micro_cases_match_reference_golden(cuda, name):
+    _, _, _, out = run_hip(name, cuda)
+    check_against_golden(name, out, "full")
+
+
+@pytest.mark.parametrize("name", ["vits_224x280_t2", "vits_224x280_conv_t2", "vits_518_t4"])
+def test_full_size_cases_match_reference_golden(cuda, name):
+    _, _, _, out = run_hip(name, cuda)
+    check_against_golden(name, out, "strided", all_pixels=True)
+
+
+def _stage_report(model, kwargs, x, cuda):
+    """Per-stage scale-relative error of the HIP path against the CPU oracle."""
+    cfg = H.oracle_config(kwargs)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    stages = {}
+    with torch.no_grad():
+        ref = orc.forward(sd, x.cpu(), cfg, stages)
+    Fr = x.shape[0] * x.shape[1]
+    rows = []
+    for k in ("tokens", "block0", "tap0", "tap1", "tap2", "tap3", "mm0", "mm1", "path4", "path3", "path2", "path1"):
+        if k not in stages:
+            continue
+        r = stages[k]
+        got = model.stage(k).cpu()
+        if r.dim() == 4:  # oracle NCHW -> channels-last
+            r = r.permute(0, 2, 3, 1).contiguous()
+        assert got.numel() == r.numel(), (k, got.numel(), r.numel())
+        rows.append((k, H.rel_err(got.reshape(r.shape).numpy(), r.numpy())))
+    return ref, rows
+
+
+@pytest.mark.parametrize("name", ["micro_vda_dvlora", "micro_conv_dvlora", "micro_vitl", "micro_t32", "micro_vda_lora_b2"])
+def test_stages_against_oracle(cuda, name):
+    model, kwargs, x, out = run_hip(name, cuda, capture=True)
+    ref, rows = _stage_report(model, kwargs, x, cuda)
+    report = ", ".join(f"{k}={e:.1e}" for k, e in rows)
+    print(f"\n[{name}] stage errors: {report}")
+    for k, e in rows:
+        assert e <= 1e-4, f"{name}: first divergent stage {k} ({e:.3e}); all: {report}"
+    for s in range(4):
+        e = H.rel_err(out[("disp", s)].cpu().numpy(), ref[("disp", s)].numpy())
+        assert e <= DISP_RTOL, f"{name} disp{s} vs oracle: {e:.3e}"
+
+
+def test_baseline_config_vits_518_t8_against_oracle(cuda):
+    """BASELINE config 2 (ViT-S, 518x518, T=8) at full size: HIP vs the CPU oracle on this box,
+    and the BASELINE quality metric abs_rel of build depth against reference depth."""
+    import endodav_amd
+    from endodav_amd import synth
+
+    kwargs = dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384], image_shape=(518, 518), lora_type="dvlora", disable_conv_head=True)
+    model = endodav_amd.endodav(**kwargs).eval()
+    synth.fill_module_(model)
+    x = torch.from_numpy(synth.synth_clip(1, 8, 518, 518, seed=2, kind="tissue"))
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        ref = orc.forward(sd, x, H.oracle_config(kwargs))
+    model = model.to(cuda)
+    with torch.no_grad():
+        out = model(x.to(cuda))
+    for s in range(4):
+        a, b = out[("disp", s)].cpu().numpy(), ref[("disp", s)].numpy()
+        assert a.shape == b.shape
+        e, de, ar = H.rel_err(a, b), H.depth_rel_err(a, b), H.abs_rel(a, b)
+        print(f"\n[vits 518 T=8] disp{s}: scale-rel {e:.2e}, max depth rel (all pixels) {de:.2e}, abs_rel {ar:.2e}")
+        assert e <= DISP_RTOL and de <= DEPTH_RTOL and ar <= ABS_REL_MAX
+
+
+def test_weights_update_is_seen(cuda):
+    """An optimizer-style in-place update of a bound tensor must re-fold the LoRA weights."""
+    model, kwargs, x, out0 = run_hip("micro_vda_dvlora", cuda)
+    with torch.no_grad():
+        model.pretrained.blocks[3].mlp.fc1.lora_B.mul_(1.5)
+        out1 = model(x)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        ref = orc.forward(sd, x.cpu(), H.oracle_config(kwargs))
+    assert H.rel_err(out1[("disp", 0)].cpu().numpy(), ref[("disp", 0)].numpy()) <= DISP_RTOL
+    assert (out1[("disp", 0)] - out0[("disp", 0)]).abs().max() > 0
+
+
+def test_errors_are_loud(cuda):
+    import endodav_amd
+
+    model, kwargs, x, _ = run_hip("micro_vda_dvlora", cuda)
+    with pytest.raises(RuntimeError):  # CPU tensor: no fallback
+        model(x.cpu())
+    with pytest.raises(RuntimeError):  # T > num_frames (motion_module.py:197)
+        with torch.no_grad():
+            model(torch.rand(1, 33, 3, 42, 56, device=cuda))
+    with pytest.raises(KeyError):
+        endodav_amd.endodav(encoder="vitx")
+    with pytest.raises(NotImplementedError):  # grads enabled + trainable LoRA: backward is not built
+        model(x)

@@ -1,0 +1,295 @@
+"""Per-kernel parity on MI355X: every C-ABI kernel entry point against the plain PyTorch fp32/fp64 op
+the reference calls.  All calls go through ctypes -> libendodav_hip.so."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from endodav_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(*shape, generator=g) * 2 - 1) * scale
+
+
+def st():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def close(a, b, rtol, what=""):
+    a, b = a.double().cpu(), b.double().cpu()
+    err = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+    assert err <= rtol, f"{what}: scale-relative error {err:.3e} > {rtol:.1e}"
+    return err
+
+
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,dim", [(1000, 384), (777, 1024), (513, 64), (129, 32), (5, 768), (300, 192)])
+def test_layernorm(lib, cuda, rows, dim):
+    x, w, b = rnd(rows, dim, seed=1, scale=3) + 0.5, rnd(dim, seed=2) + 1.0, rnd(dim, seed=3, scale=0.1)
+    ref = F.layer_norm(x.double(), (dim,), w.double(), b.double(), 1e-6)
+    xd, wd, bd = x.to(cuda), w.to(cuda), b.to(cuda)
+    y = torch.empty_like(xd)
+    _lib.check(lib.edv_layernorm(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), rows, dim, 1e-6, None, 0, 0, st()))
+    close(y, ref, 2e-6, "layernorm")
+
+
+def test_layernorm_with_temporal_pe(lib, cuda):
+    Bc, T, P, Cc = 2, 5, 37, 64
+    rows = Bc * T * P
+    x, w, b, pe = rnd(rows, Cc, seed=1), rnd(Cc, seed=2) + 1, rnd(Cc, seed=3, scale=0.1), rnd(32, Cc, seed=4)
+    ref = F.layer_norm(x, (Cc,), w, b, 1e-5).reshape(Bc, T, P, Cc) + pe[:T].reshape(1, T, 1, Cc)
+    xd, wd, bd, ped = (t.to(cuda) for t in (x, w, b, pe))
+    y = torch.empty_like(xd)
+    _lib.check(lib.edv_layernorm(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), rows, Cc, 1e-5, ped.data_ptr(), P, T, st()))
+    close(y, ref.reshape(rows, Cc), 2e-6, "layernorm+pe")
+
+
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,act,use_bias,use_gamma,use_res", [
+    (300, 384, 384, 0, True, False, False),
+    (2 * 1370, 1152, 384, 0, True, False, False),     # qkv
+    (2 * 1370, 384, 1536, 0, True, True, True),       # fc2 + LayerScale + residual
+    (1370, 1536, 384, 1, True, False, False),         # fc1 + GELU
+    (8 * 1370, 1536, 384, 1, True, False, False),     # 128x128 tile path
+    (2 * 1369, 384, 588, 0, True, False, True),       # patch-embed (K tail: 588 = 18*32 + 12)
+    (257, 48, 384, 0, True, False, False),            # N not a multiple of 32
+    (1000, 32, 144, 2, True, False, False),           # N = 32 tile, ReLU
+    (999, 16, 64, 0, False, False, False),            # N < 32
+    (3, 96, 96, 0, True, False, False),               # tiny M
+    (5000, 768, 48, 0, True, False, False),           # ConvT-like
+])
+def test_gemm(lib, cuda, M, N, K, act, use_bias, use_gamma, use_res):
+    A, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K))
+    bias = rnd(N, seed=3, scale=0.1) if use_bias else None
+    gamma = rnd(N, seed=4) + 1.2 if use_gamma else None
+    R = rnd(M, N, seed=5) if use_res else None
+    ref = A.double() @ W.double().T
+    if bias is not None:
+        ref = ref + bias.double()
+    if act == 1:
+        ref = F.gelu(ref)
+    elif act == 2:
+        ref = F.relu(ref)
+    if gamma is not None:
+        ref = ref * gamma.double()
+    if R is not None:
+        ref = ref + R.double()
+    d = lambda t: None if t is None else t.to(cuda)
+    Ad, Wd, bd, gd, Rd = d(A), d(W), d(bias), d(gamma), d(R)
+    Cd = torch.full((M, N), float("nan"), device=cuda)
+    _lib.check(lib.edv_gemm(Ad.data_ptr(), Wd.data_ptr(), Cd.data_ptr(), M, N, K, _lib.ptr(bd), act, _lib.ptr(gd), _lib.ptr(Rd), st()), "edv_gemm")
+    close(Cd, ref, 3e-6, f"gemm {M}x{N}x{K}")
+
+
+def test_gemm_inplace_residual(lib, cuda):
+    """proj / fc2 write the residual stream in place (C aliases R)."""
+    M, N, K = 1370, 384, 384
+    A, W, X = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(M, N, seed=3)
+    ref = X.double() + A.double() @ W.double().T
+    Ad, Wd, Xd = A.to(cuda), W.to(cuda), X.to(cuda)
+    _lib.check(lib.edv_gemm(Ad.data_ptr(), Wd.data_ptr(), Xd.data_ptr(), M, N, K, None, 0, None, Xd.data_ptr(), st()))
+    close(Xd, ref, 3e-6, "in-place residual")
+
+
+def test_gemm_rejects_bad_k(lib, cuda):
+    a = torch.zeros(8, 6, device=cuda)
+    assert lib.edv_gemm(a.data_ptr(), a.data_ptr(), a.data_ptr(), 8, 8, 6, None, 0, None, None, st()) != 0
+    assert b"multiple of 4" in lib.edv_last_error()
+
+
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Fr,H,W,Cin,Cout,stride,pre,post,res", [
+    (2, 19, 23, 48, 64, 1, False, False, 0),
+    (2, 37, 37, 384, 384, 2, False, False, 0),   # resize_layers[3]
+    (3, 20, 16, 64, 64, 1, True, False, 2),      # ResidualConvUnit conv2 + both skip adds
+    (1, 74, 74, 64, 32, 1, False, False, 0),     # output_conv1
+    (1, 70, 98, 32, 32, 1, False, True, 0),      # output_conv2.0 + ReLU
+    (2, 5, 7, 16, 32, 1, False, True, 0),        # micro head
+    (2, 1, 2, 64, 64, 2, False, False, 1),       # degenerate grid
+])
+def test_conv3x3(lib, cuda, Fr, H, W, Cin, Cout, stride, pre, post, res):
+    x = rnd(Fr, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=1 / math.sqrt(9 * Cin))
+    b = rnd(Cout, seed=3, scale=0.1)
+    xin = F.relu(x) if pre else x
+    ref = F.conv2d(xin.double(), w.double(), b.double(), stride=stride, padding=1)
+    if post:
+        ref = F.relu(ref)
+    OH, OW = ref.shape[-2:]
+    R1 = rnd(Fr, Cout, OH, OW, seed=4) if res >= 1 else None
+    R2 = rnd(Fr, Cout, OH, OW, seed=5) if res >= 2 else None
+    for r in (R1, R2):
+        if r is not None:
+            ref = ref + r.double()
+    nhwc = lambda t: None if t is None else t.permute(0, 2, 3, 1).contiguous().to(cuda)
+    xd, wd, bd, r1, r2 = nhwc(x), w.to(cuda), b.to(cuda), nhwc(R1), nhwc(R2)
+    wp = torch.empty(Cout * 9 * Cin, device=cuda)
+    _lib.check(lib.edv_pack_conv3x3(wd.data_ptr(), wp.data_ptr(), Cout, Cin, st()))
+    y = torch.full((Fr, OH, OW, Cout), float("nan"), device=cuda)
+    _lib.check(lib.edv_conv3x3(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), y.data_ptr(), Fr, H, W, Cin, Cout, stride, int(pre), int(post),
+                               _lib.ptr(r1), _lib.ptr(r2), st()), "edv_conv3x3")
+    close(y.permute(0, 3, 1, 2), ref, 3e-6, "conv3x3")
+
+
+@pytest.mark.parametrize("Fr,h,w,Cc,s", [(2, 37, 37, 48, 4), (2, 16, 20, 96, 2), (1, 3, 4, 32, 4)])
+def test_conv_transpose(lib, cuda, Fr, h, w, Cc, s):
+    x, wt, b = rnd(Fr, Cc, h, w, seed=1), rnd(Cc, Cc, s, s, seed=2, scale=1 / math.sqrt(Cc)), rnd(Cc, seed=3, scale=0.1)
+    ref = F.conv_transpose2d(x.double(), wt.double(), b.double(), stride=s)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(cuda)
+    wd, bd = wt.to(cuda), b.to(cuda)
+    wp, bp = torch.empty(s * s * Cc * Cc, device=cuda), torch.empty(s * s * Cc, device=cuda)
+    y = torch.full((Fr, h * s, w * s, Cc), float("nan"), device=cuda)
+    _lib.check(lib.edv_conv_transpose(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), wp.data_ptr(), bp.data_ptr(), y.data_ptr(), Fr, h, w, Cc, s, st()))
+    close(y.permute(0, 3, 1, 2), ref, 3e-6, "convT")
+
+
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Fr,N,heads", [(2, 1370, 6), (1, 64, 2), (3, 10, 1), (1, 129, 12), (2, 321, 6), (1, 1369, 16)])
+def test_attn_spatial(lib, cuda, Fr, N, heads):
+    D = heads * 64
+    qkv = rnd(Fr * N, 3 * D, seed=1, scale=2.0)
+    t = qkv.double().reshape(Fr, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    q, k, v = t[0] * 64 ** -0.5, t[1], t[2]
+    ref = ((q @ k.transpose(-2, -1)).softmax(-1) @ v).transpose(1, 2).reshape(Fr * N, D)
+    qd = qkv.to(cuda)
+    o = torch.full((Fr * N, D), float("nan"), device=cuda)
+    _lib.check(lib.edv_attn_spatial(qd.data_ptr(), o.data_ptr(), Fr, N, heads, st()), "edv_attn_spatial")
+    close(o, ref, 5e-6, "attn_spatial")
+
+
+def test_attn_spatial_peaked_rows(lib, cuda):
+    """Online-softmax rescale path: one key dominates, and it sits in a LATE tile for some rows."""
+    Fr, N, heads, D = 1, 300, 1, 64
+    qkv = rnd(Fr * N, 3 * D, seed=7, scale=0.5)
+    qkv[:, :64] *= 6.0
+    qkv[250, 64:128] *= 12.0  # key 250 (4th tile) gets very large scores against many queries
+    t = qkv.double().reshape(Fr, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    ref = (((t[0] * 0.125) @ t[1].transpose(-2, -1)).softmax(-1) @ t[2]).transpose(1, 2).reshape(Fr * N, D)
+    qd = qkv.to(cuda)
+    o = torch.empty((Fr * N, D), device=cuda)
+    _lib.check(lib.edv_attn_spatial(qd.data_ptr(), o.data_ptr(), Fr, N, heads, st()))
+    close(o, ref, 5e-6, "attn_spatial peaked")
+
+
+@pytest.mark.parametrize("Bc,T,P,Cc", [(1, 8, 37 * 37, 192), (2, 3, 50, 64), (1, 16, 19 * 19, 384), (1, 32, 41, 32), (1, 1, 9, 64), (2, 32, 30, 256)])
+def test_attn_temporal(lib, cuda, Bc, T, P, Cc):
+    heads, d = 8, Cc // 8
+    qkv = rnd(Bc * T * P, 3 * Cc, seed=1, scale=1.5)
+    t = qkv.double().reshape(Bc, T, P, 3, heads, d).permute(3, 0, 2, 4, 1, 5)  # [3, B, P, h, T, d]
+    a = ((t[0] @ t[1].transpose(-1, -2)) * d ** -0.5).softmax(-1)
+    ref = (a @ t[2]).permute(0, 3, 1, 2, 4).reshape(Bc * T * P, Cc)  # [B, T, P, h, d]
+    qd = qkv.to(cuda)
+    o = torch.full((Bc * T * P, Cc), float("nan"), device=cuda)
+    _lib.check(lib.edv_attn_temporal(qd.data_ptr(), o.data_ptr(), Bc, T, P, Cc, heads, st()), "edv_attn_temporal")
+    close(o, ref, 3e-6, "attn_temporal")
+
+
+def test_attn_temporal_rejects_long_clips(lib, cuda):
+    z = torch.zeros(33 * 8 * 3 * 64, device=cuda)
+    assert lib.edv_attn_temporal(z.data_ptr(), z.data_ptr(), 1, 33, 8, 64, 8, st()) != 0
+
+
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("Fr,P,Cc", [(3, 25, 64), (2, 1369, 192), (2, 361, 384), (4, 6, 32), (1, 5476, 64)])
+def test_groupnorm(lib, cuda, Fr, P, Cc):
+    x = rnd(Fr, P, Cc, seed=1, scale=2) + 3.0  # mean >> std: one-pass E[x^2]-E[x]^2 would lose digits
+    w, b = rnd(Cc, seed=2) + 1, rnd(Cc, seed=3, scale=0.1)
+    ref = F.group_norm(x.double().permute(0, 2, 1), 32, w.double(), b.double(), 1e-6).permute(0, 2, 1)
+    xd, wd, bd = x.to(cuda), w.to(cuda), b.to(cuda)
+    y, stats = torch.empty_like(xd), torch.empty(Fr * 32 * 2, device=cuda)
+    _lib.check(lib.edv_groupnorm(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), stats.data_ptr(), Fr, P, Cc, 32, 1e-6, st()))
+    close(y, ref, 5e-6, "groupnorm")
+
+
+def test_geglu(lib, cuda):
+    M, inner = 777, 256
+    x = rnd(M, 2 * inner, seed=1, scale=3)
+    ref = x[:, :inner].double() * F.gelu(x[:, inner:].double())
+    xd = x.to(cuda)
+    y = torch.empty(M, inner, device=cuda)
+    _lib.check(lib.edv_geglu(xd.data_ptr(), y.data_ptr(), M, inner, st()))
+    close(y, ref, 2e-6, "geglu")
+
+
+@pytest.mark.parametrize("Fr,H,W,Cc,OH,OW", [(2, 19, 19, 64, 37, 37), (1, 296, 296, 32, 518, 518), (2, 518, 518, 1, 259, 259), (2, 129, 129, 1, 64, 64),
+                                             (1, 16, 20, 64, 32, 40), (2, 1, 2, 32, 3, 4), (1, 7, 9, 4, 7, 9), (3, 37, 37, 1, 480, 640)])
+def test_bilinear(lib, cuda, Fr, H, W, Cc, OH, OW):
+    x = rnd(Fr, Cc, H, W, seed=1)
+    ref = F.interpolate(x, size=(OH, OW), mode="bilinear", align_corners=True)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(cuda)
+    y = torch.empty(Fr, OH, OW, Cc, device=cuda)
+    _lib.check(lib.edv_bilinear(xd.data_ptr(), y.data_ptr(), Fr, H, W, Cc, OH, OW, st()))
+    close(y.permute(0, 3, 1, 2), ref, 2e-6, "bilinear")
+
+
+@pytest.mark.parametrize("act", [0, 2, 3, 4])
+def test_dot_channels(lib, cuda, act):
+    M, Cc = 12345, 32
+    x, w, b = rnd(M, Cc, seed=1), rnd(Cc, seed=2), rnd(1, seed=3)
+    ref = x.double() @ w.double() + b.double()
+    ref = {0: ref, 2: F.relu(ref), 3: torch.sigmoid(ref), 4: torch.sigmoid(-ref)}[act]
+    xd, wd, bd = x.to(cuda), w.to(cuda), b.to(cuda)
+    y = torch.empty(M, device=cuda)
+    _lib.check(lib.edv_dot_channels(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), M, Cc, act, st()))
+    close(y, ref, 2e-6, "dot_channels")
+
+
+@pytest.mark.parametrize("H,W,ih,iw", [(518, 518, 518, 518), (256, 320, 224, 280), (64, 80, 42, 56), (30, 50, 42, 42)])
+def test_patchify(lib, cuda, H, W, ih, iw):
+    Fr = 2
+    x = torch.rand(Fr, 3, H, W, generator=torch.Generator().manual_seed(3))
+    xr = F.interpolate(x, size=(ih, iw), mode="bilinear", align_corners=True)
+    xn = (xr - torch.tensor([0.485, 0.456, 0.406])[None, :, None, None]) / torch.tensor([0.229, 0.224, 0.225])[None, :, None, None]
+    ref = F.unfold(xn, kernel_size=14, stride=14).transpose(1, 2).reshape(-1, 588)  # rows (f, py, px), cols (c, ky, kx)
+    xd = x.to(cuda)
+    cols = torch.empty(ref.shape, device=cuda)
+    _lib.check(lib.edv_patchify(xd.data_ptr(), cols.data_ptr(), Fr, H, W, ih, iw, st()))
+    close(cols, ref, 2e-6, "patchify")
+
+
+@pytest.mark.parametrize("S,oh,ow", [(37, 16, 20), (16, 37, 37), (37, 3, 4), (16, 3, 4), (37, 37, 37)])
+def test_bicubic_pos(lib, cuda, S, oh, ow):
+    D = 64
+    g = rnd(S, S, D, seed=1)
+    sh, sw = (oh + 0.1) / math.sqrt(S * S), (ow + 0.1) / math.sqrt(S * S)
+    ref = F.interpolate(g.permute(2, 0, 1)[None], scale_factor=(sh, sw), mode="bicubic")[0].permute(1, 2, 0)
+    assert ref.shape[:2] == (oh, ow)
+    gd = g.to(cuda)
+    out = torch.empty(oh, ow, D, device=cuda)
+    _lib.check(lib.edv_bicubic_pos(gd.data_ptr(), out.data_ptr(), S, D, oh, ow, sh, sw, st()))
+    close(out, ref, 3e-6, "bicubic_pos")
+
+
+@pytest.mark.parametrize("H,W,OH,OW", [(480, 640, 518, 686), (1024, 1280, 518, 644), (50, 60, 100, 120)])
+def test_resize_bicubic(lib, cuda, H, W, OH, OW):
+    x = torch.rand(3, 1, H, W, generator=torch.Generator().manual_seed(5))
+    ref = F.interpolate(x, size=(OH, OW), mode="bicubic", align_corners=False)
+    xd = x.to(cuda)
+    y = torch.empty(3, 1, OH, OW, device=cuda)
+    _lib.check(lib.edv_resize_bicubic(xd.data_ptr(), y.data_ptr(), 3, H, W, OH, OW, st()))
+    close(y, ref, 3e-6, "resize_bicubic")
+
+
+@pytest.mark.parametrize("dv", [False, True])
+def test_fold_lora(lib, cuda, dv):
+    nout, nin, r = 1536, 384, 4
+    W, A, Bm = rnd(nout, nin, seed=1, scale=0.05), rnd(r, nin, seed=2, scale=0.1), rnd(nout, r, seed=3)
+    U, V = (rnd(r, 1, seed=4) + 1, rnd(nout, 1, seed=5) + 1) if dv else (None, None)
+    scale = 1.0 if dv else 2.0
+    ref = W.double() + scale * ((Bm * V).double() @ (A * U).double() if dv else Bm.double() @ A.double())
+    d = lambda t: None if t is None else t.to(cuda)
+    Wd, Ad, Bd, Ud, Vd = d(W), d(A), d(Bm), d(U), d(V)
+    out = torch.empty(nout, nin, device=cuda)
+    _lib.check(lib.edv_fold_lora(Wd.data_ptr(), Ad.data_ptr(), Bd.data_ptr(), _lib.ptr(Ud), _lib.ptr(Vd), scale, out.data_ptr(), nout, nin, r, st()))
+    close(out, ref, 2e-6, "fold_lora")
+    # the fold is equivalent to the reference's side product x A^T B^T (mylora/layers.py:152-155)
+    x = rnd(64, nin, seed=9)
+    side = x.double() @ W.double().T + scale * (x.double() @ ((A * U) if dv else A).double().T @ ((Bm * V) if dv else Bm).double().T)
+    close(x.double() @ out.double().cpu().T, side, 1e-6, "fold == side product")

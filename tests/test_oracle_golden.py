@@ -1,0 +1,54 @@
+"""CPU: the oracle replayed against the golden fixtures captured from the imported reference.
+
+The weights are regenerated from ``endodav_amd.synth`` INTO THE BUILD'S OWN MODULE TREE, so a green run
+also proves that the build's state_dict has the reference's key names and shapes (a wrong or missing key
+would change the hash-initialised weights and the output)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import endodav_oracle as orc
+from tests import helpers as H
+from tests.golden.cases import CASES, STAGE_KEYS
+
+FAST = [n for n in CASES if n.startswith("micro_")]
+FULL = [n for n in CASES if not n.startswith("micro_")]
+
+
+def _replay(name):
+    model, kwargs, shape, kind, store = H.build_model(name)
+    x = H.case_input(name)
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    stages = {}
+    with torch.no_grad():
+        out = orc.forward(sd, x, H.oracle_config(kwargs), stages)
+    g = H.load_golden(name)
+    assert float(g["oracle_vs_reference_maxrel"]) < 2e-5  # recorded when the fixture was made
+    for s in range(4):
+        a = out[("disp", s)].numpy()
+        ref = g[f"disp{s}"]
+        cmp = a if store == "full" else a[..., ::7, ::7]
+        assert cmp.shape == ref.shape
+        assert H.rel_err(cmp, ref) < 2e-5, f"{name} disp{s}"
+        assert np.allclose(H.frame_stats(a), g[f"disp{s}_stats"], rtol=1e-4, atol=1e-5)
+    for sk in STAGE_KEYS:
+        if f"stage_{sk}_stats" in g:
+            assert np.allclose(H.frame_stats(stages[sk].numpy()), g[f"stage_{sk}_stats"], rtol=2e-4, atol=2e-5), f"{name} stage {sk}"
+
+
+@pytest.mark.parametrize("name", FAST)
+def test_oracle_matches_reference_golden_micro(name):
+    _replay(name)
+
+
+@pytest.mark.slow
+@pytest.mark.parametrize("name", FULL)
+def test_oracle_matches_reference_golden_full(name):
+    _replay(name)
+
+
+def test_disp_to_depth_known_answers():
+    # utils/layers.py:11-20 with the trainer's min/max depth 0.1 / 150
+    scaled, depth = orc.disp_to_depth(np.array([0.0, 1.0, 0.5]))
+    assert np.allclose(depth, [150.0, 0.1, 1.0 / (1 / 150 + (10 - 1 / 150) * 0.5)])
+    assert np.allclose(scaled, [1 / 150, 10.0, 1 / 150 + (10 - 1 / 150) * 0.5])

@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""bench.py — frames/s of EndoDAV's per-clip forward on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--T 8] [--encoder vits]
+
+One "step" = one pass of the hot path (edv_forward) over one synthetic 518x518 clip of T frames that is
+already resident in HBM.  N > 1: one process per GPU (torch.distributed.run), every rank runs its own
+clip per step, no data-path collective (clips are independent: SURVEY.md §8e) — weak scaling; the only
+NCCL(RCCL) traffic is the barrier and the MAX-reduction of the elapsed time around the timed region.
+
+Rank 0 prints ONE JSON line: value = total frames of all ranks / max-over-ranks time, plus
+  roofline      the dominant kernel (spatial attention, fp32 MFMA) priced as algorithmic FLOPs per launch over
+                its mean launch time, measured with HIP event pairs on the launch stream inside the timed region
+  cpu_baseline  the oracle (PyTorch-CPU restatement, kind "port") timed on this box's host cores on a bounded
+                sample of the same workload (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+VITS = dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384])
+VITB = dict(encoder="vitb", features=128, out_channels=[96, 192, 384, 768])
+VITL = dict(encoder="vitl", features=256, out_channels=[256, 512, 1024, 1024])
+MODELS = {"vits": VITS, "vitb": VITB, "vitl": VITL}
+DIMS = {"vits": (384, 12, 6), "vitb": (768, 12, 12), "vitl": (1024, 24, 16)}
+# matmul+conv FLOPs per 518x518 frame, FlopCounterMode over the reference
+GFLOP_PER_FRAME = {"vits": 121.1, "vitb": 403.9, "vitl": 1403.8}
+PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--T", type=int, default=8, help="frames per clip (BASELINE headline: 8)")
+    ap.add_argument("--encoder", default="vits", choices=sorted(MODELS))
+    ap.add_argument("--image", type=int, default=518)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with HIP events")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(16, cores): the box's CPU share)")
+    return ap.parse_args()
+
+
+def cpu_baseline(kwargs, T, image, threads):
+    """Oracle on the host cores: 1 warm-up clip + timed clips until ~20 s or 3 clips."""
+    import torch
+
+    import endodav_amd
+    from endodav_amd import synth
+    from oracle import endodav_oracle as orc
+
+    cores = threads or min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    model = endodav_amd.endodav(**kwargs, image_shape=(image, image), lora_type="dvlora", disable_conv_head=True).eval()
+    synth.fill_module_(model)
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    cfg = orc.OracleConfig(encoder=kwargs["encoder"], image_shape=(image, image), lora_type="dvlora", disable_conv_head=True)
+    x = torch.from_numpy(synth.synth_clip(1, T, image, image, seed=0))
+    with torch.no_grad():
+        orc.forward(sd, x, cfg)  # warm-up
+        n, t0 = 0, time.perf_counter()
+        while n < 3 and (n == 0 or time.perf_counter() - t0 < 20.0):
+            orc.forward(sd, x, cfg)
+            n += 1
+        dt = time.perf_counter() - t0
+    return {"value": round(n * T / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"{n} clip(s) of T={T} at {image}x{image} after 1 warm-up clip, oracle/endodav_oracle.py (torch {torch.__version__} CPU fp32)"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    import endodav_amd
+    from endodav_amd import synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    kwargs = MODELS[args.encoder]
+    T, S = args.T, args.image
+    model = endodav_amd.endodav(**kwargs, image_shape=(S, S), lora_type="dvlora", disable_conv_head=True).eval()
+    synth.fill_module_(model)
+    model = model.to(dev)
+    x = torch.from_numpy(synth.synth_clip(1, T, S, S, seed=rank)).to(dev)  # resident in HBM before timing
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+
+    with torch.no_grad():
+        for _ in range(max(args.warmup, 1)):
+            out = model(x)
+        sync_all()
+        if not args.no_kernel_events:
+            model.profile_enable(["attn_spatial"])
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = model(x)
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    roofline = None
+    if not args.no_kernel_events:
+        n, ms = model.profile_read("attn_spatial")
+        D, depth, heads = DIMS[args.encoder]
+        ntok = (S // 14) ** 2 + 1
+        flops = 4.0 * ntok * ntok * 64 * heads * T  # QK^T + PV, 2 FLOP per MAC, per launch (one encoder block, T frames)
+        if n > 0 and ms > 0:
+            achieved = flops / (ms / n * 1e-3) / 1e12
+            roofline = {"kernel": "attn_spatial_kernel", "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "launches": n, "avg_launch_ms": round(ms / n, 4), "flop_per_launch": flops,
+                        "peak_dtype": "f32 MFMA (v_mfma_f32_32x32x2_f32), dense"}
+    finite = bool(torch.isfinite(out[("disp", 0)]).all().item())
+    if rank == 0:
+        frames = world * T * args.steps
+        value = frames / dt
+        line = {
+            "metric": "depth frames/sec (518x518, T=8 clip)" if (S, T) == (518, 8) else f"depth frames/sec ({S}x{S}, T={T} clip)",
+            "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ViT-{args.encoder[-1].upper()} endodav (features {kwargs['features']}, out_channels {kwargs['out_channels']}, "
+                                   f"dvlora r=4, VDA head), one synthetic {S}x{S} T={T} clip per GPU per step (BASELINE.json configs[1] shape), "
+                                   "hash-initialised weights", "encoder": args.encoder, "T": T, "image": [S, S], "clips_per_gpu_per_step": 1,
+                       "parallelism": f"clip-sharded x{world}, no data-path collective"},
+            "model_tflop_per_clip": round(GFLOP_PER_FRAME[args.encoder] * T / 1e3 * (S / 518.0) ** 2, 4),
+            "model_tflops": round(GFLOP_PER_FRAME[args.encoder] * (S / 518.0) ** 2 * value / 1e3, 2),
+            "launches_per_step": model.launch_count(), "device_mem_mb": round(model.device_bytes() / 2 ** 20, 1), "output_finite": finite,
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(kwargs, T, S, args.cpu_threads)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -58,6 +58,8 @@ SIGNATURES = {
     "edv_output_shape": (C.c_int, [C.c_void_p, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "edv_stage_copy": (C.c_int, [C.c_void_p, C.c_char_p, _fp, C.POINTER(C.c_size_t), C.c_void_p]),
     "edv_set_capture": (C.c_int, [C.c_void_p, C.c_int]),
+    "edv_profile_enable": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "edv_profile_read": (C.c_int, [C.c_void_p, _i32, C.POINTER(_i32), C.POINTER(_f64)]),
     "edv_device_bytes": (C.c_size_t, [C.c_void_p]),
     "edv_last_launch_count": (C.c_int, [C.c_void_p]),
     "edv_layernorm": (C.c_int, [_fp, _fp, _fp, _fp, _i64, _i32, _f32, _fp, _i32, _i32, C.c_void_p]),
@@ -76,6 +78,9 @@ SIGNATURES = {
     "edv_resize_bicubic": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
     "edv_fold_lora": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _f32, _fp, _i32, _i32, _i32, C.c_void_p]),
 }
+
+
+KERNEL_CLASSES = {"linear": 0, "conv3x3": 1, "attn_spatial": 2, "attn_temporal": 3, "layernorm": 4, "other": 5}
 
 
 class EdvError(RuntimeError):

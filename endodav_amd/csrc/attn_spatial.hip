@@ -15,6 +15,9 @@
 // feed the second product straight from the accumulator registers: the accumulator's row map
 // key = (r&3) + 8*(r>>2) + 4*(lane>>5) assigns register r of lane-half h exactly the k-slot h
 // of MFMA step r, so no data moves between the two products.
+#include <cmath>
+#include <cstdlib>
+
 #include "ops.hpp"
 
 namespace edv {
@@ -26,9 +29,12 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int HD = 64;       // head dim
 constexpr int KT = 64;       // keys per LDS tile
 constexpr int KS = HD + 4;   // padded K row stride: 68r mod 64 = 4r -> conflict-free b128
-constexpr int QB = 128;      // queries per workgroup
-
-__global__ __launch_bounds__(256) void attn_spatial_kernel(const float *__restrict__ qkv, float *__restrict__ out, int N, int heads) {
+// NW waves per workgroup (NW*32 queries share the staged K/V tiles).  Fewer waves per workgroup means more,
+// smaller workgroups: better balance over the 256 CUs when frames*heads*ceil(N/128) is only ~2 per CU.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void attn_spatial_kernel(const float *__restrict__ qkv, float *__restrict__ out, int N, int heads) {
+    constexpr int QB = NW * 32;
+    constexpr int NT = NW * 64;
     __shared__ __attribute__((aligned(16))) float smem[KT * KS + KT * HD];
     float *sK = smem;
     float *sV = smem + KT * KS;
@@ -56,13 +62,14 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const float *__restri
     for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    // staging slots: 16 float4 per 64-float row; thread -> (row sr + 16*i, chunk sc)
+    // staging slots: 16 float4 per 64-float row; thread -> (row sr + RS*i, chunk sc)
+    constexpr int RS = NT / 16, RI = KT / RS;  // rows per pass, passes
     const int sc = tid & 15, sr = tid >> 4;
-    f32x4 rk[4], rv[4];
+    f32x4 rk[RI], rv[RI];
     auto load_tile = [&](int k0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            int kr = k0 + sr + 16 * i;
+        for (int i = 0; i < RI; ++i) {
+            int kr = k0 + sr + RS * i;
             kr = kr < N ? kr : N - 1;  // clamped rows are masked below
             const float *p = base + (long long)kr * D3 + sc * 4;
             rk[i] = *reinterpret_cast<const f32x4 *>(p + D);
@@ -76,9 +83,9 @@ __global__ __launch_bounds__(256) void attn_spatial_kernel(const float *__restri
         const int k0 = t * KT;
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4 *>(&sK[(sr + 16 * i) * KS + sc * 4]) = rk[i];
-            *reinterpret_cast<f32x4 *>(&sV[(sr + 16 * i) * HD + sc * 4]) = rv[i];
+        for (int i = 0; i < RI; ++i) {
+            *reinterpret_cast<f32x4 *>(&sK[(sr + RS * i) * KS + sc * 4]) = rk[i];
+            *reinterpret_cast<f32x4 *>(&sV[(sr + RS * i) * HD + sc * 4]) = rv[i];
         }
         __syncthreads();
         if (t + 1 < ntiles) load_tile(k0 + KT);
@@ -162,8 +169,22 @@ int attn_spatial(const float *qkv, float *out, int F, int N, int heads, hipStrea
     EDV_CHECK(F > 0 && N > 0 && heads > 0, "empty problem");
     EDV_CHECK(F <= 65535 && heads <= 65535, "grid limits");
     EDV_CHECK(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 16 == 0), "16-byte alignment");
-    dim3 grid((N + QB - 1) / QB, heads, F), block(256);
-    hipLaunchKernelGGL(attn_spatial_kernel, grid, block, 0, st, qkv, out, N, heads);
+    // 4 waves (128 queries) per workgroup share each staged K/V tile.  The 2- and 1-wave variants give a finer
+    // grid but cost registers (195 / 256 VGPRs) and measured slower on every shape tried (T=8: 79.9 vs 78.6 vs
+    // 68.5 TF/s); they are kept for sequences shorter than one 128-query block and for experiments.
+    static const int forced = [] {
+        const char *e = getenv("EDV_ATTN_WAVES");
+        return e ? atoi(e) : 0;
+    }();
+    int nw = N > 64 ? 4 : (N > 32 ? 2 : 1);
+    if (forced == 1 || forced == 2 || forced == 4) nw = forced;
+    dim3 grid((N + nw * 32 - 1) / (nw * 32), heads, F);
+    if (nw == 4)
+        hipLaunchKernelGGL(attn_spatial_kernel<4>, grid, dim3(256), 0, st, qkv, out, N, heads);
+    else if (nw == 2)
+        hipLaunchKernelGGL(attn_spatial_kernel<2>, grid, dim3(128), 0, st, qkv, out, N, heads);
+    else
+        hipLaunchKernelGGL(attn_spatial_kernel<1>, grid, dim3(64), 0, st, qkv, out, N, heads);
     EDV_LAUNCH_OK();
     return 0;
 }

@@ -41,8 +41,17 @@ struct Buf {
     size_t cap = 0;  // floats
 };
 
+// kernel classes for the optional HIP-event bracketing (edv_profile_enable / edv_profile_read)
+enum { KC_LINEAR = 0, KC_CONV3 = 1, KC_ATTN_SPATIAL = 2, KC_ATTN_TEMPORAL = 3, KC_NORM = 4, KC_OTHER = 5, KC_COUNT = 6 };
+struct EvPool {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+    size_t used = 0;
+};
+
 struct edv_ctx {
     edv_config cfg{};
+    unsigned prof_mask = 0;
+    EvPool prof[KC_COUNT];
     std::unordered_map<std::string, Param> params;
     std::unordered_map<std::string, Buf> packed;  // derived weights, owned
     std::unordered_map<std::string, Buf> ws;      // activations, owned
@@ -76,6 +85,28 @@ int alloc_buf(edv_ctx *c, std::unordered_map<std::string, Buf> &pool, const std:
     *out = b.p;
     return 0;
 }
+
+// Records a start/stop event pair around one launch when its class is being profiled.  The events sit on
+// the launch stream, so the pair measures that kernel's execution (plus the in-order gap before it).
+struct Bracket {
+    hipEvent_t stop = nullptr;
+    hipStream_t st;
+    Bracket(edv_ctx *c, int cls, hipStream_t s) : st(s) {
+        if (!(c->prof_mask & (1u << cls))) return;
+        EvPool &p = c->prof[cls];
+        if (p.used == p.ev.size()) {
+            hipEvent_t a, b;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            p.ev.emplace_back(a, b);
+        }
+        auto &pr = p.ev[p.used++];
+        (void)hipEventRecord(pr.first, st);
+        stop = pr.second;
+    }
+    ~Bracket() {
+        if (stop) (void)hipEventRecord(stop, st);
+    }
+};
 
 struct Run {
     edv_ctx *c;
@@ -116,6 +147,7 @@ struct Run {
         g.A = A; g.lda = K; g.W = W; g.ldw = K; g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K;
         g.bias = bias; g.act = act; g.gamma = gamma; g.R1 = R1; g.ldr1 = N;
         c->launches++;
+        Bracket b_(c, KC_LINEAR, st);
         return gemm(g, st);
     }
     int conv3(const float *x, int H, int W, int Cin, const float *wp, const float *bias, int Cout, int stride, float *y, bool pre_relu,
@@ -126,6 +158,7 @@ struct Run {
         g.bias = bias; g.act = act; g.R1 = R1; g.ldr1 = Cout; g.R2 = R2; g.ldr2 = Cout;
         g.loader = LOAD_CONV3; g.cH = H; g.cW = W; g.cC = Cin; g.cOH = OH; g.cOW = OW; g.cS = stride; g.pre_relu = pre_relu ? 1 : 0;
         c->launches++;
+        Bracket b_(c, KC_CONV3, st);
         return gemm(g, st);
     }
     int ln(const float *x, RowMap im, const std::string &prefix, float *y, long long rows, int dim, float eps, const float *pe = nullptr,
@@ -134,6 +167,7 @@ struct Run {
         EDV_TRY(param(prefix + ".weight", &w));
         EDV_TRY(param(prefix + ".bias", &b));
         c->launches++;
+        Bracket b_(c, KC_NORM, st);
         return layernorm(x, im, w, b, y, identity_map(), rows, dim, eps, pe, rpf, TT, st);
     }
 
@@ -322,7 +356,10 @@ struct Run {
             const float *wqkv;
             EDV_TRY(packedw(ab + ".qkv", &wqkv));
             EDV_TRY(linear(hn, M, C, wqkv, 3 * C, nullptr, qkv3));
-            EDV_TRY(attn_temporal(qkv3, att, B, T, P, C, 8, st));
+            {
+                Bracket b_(c, KC_ATTN_TEMPORAL, st);
+                EDV_TRY(attn_temporal(qkv3, att, B, T, P, C, 8, st));
+            }
             c->launches++;
             EDV_TRY(param(ab + ".to_out.0.weight", &w));
             EDV_TRY(param(ab + ".to_out.0.bias", &b));
@@ -436,7 +473,10 @@ struct Run {
             EDV_TRY(param(bp + ".attn.qkv.weight", &w));
             EDV_TRY(param(bp + ".attn.qkv.bias", &b));
             EDV_TRY(linear(xn, MT, D, w, 3 * D, b, qkv));
-            EDV_TRY(attn_spatial(qkv, att, F, ntok, heads, st));
+            {
+                Bracket b_(c, KC_ATTN_SPATIAL, st);
+                EDV_TRY(attn_spatial(qkv, att, F, ntok, heads, st));
+            }
             c->launches++;
             EDV_TRY(param(bp + ".attn.proj.weight", &w));
             EDV_TRY(param(bp + ".attn.proj.bias", &b));
@@ -627,11 +667,16 @@ int edv_create(const edv_config *cfg, edv_ctx **out) {
 
 int edv_destroy(edv_ctx *ctx) {
     if (!ctx) return 0;
-    hipDeviceSynchronize();
+    (void)hipDeviceSynchronize();
     for (auto &kv : ctx->packed)
-        if (kv.second.p) hipFree(kv.second.p);
+        if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto &kv : ctx->ws)
-        if (kv.second.p) hipFree(kv.second.p);
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto &p : ctx->prof)
+        for (auto &e : p.ev) {
+            (void)hipEventDestroy(e.first);
+            (void)hipEventDestroy(e.second);
+        }
     delete ctx;
     return 0;
 }
@@ -692,6 +737,31 @@ int edv_stage_copy(edv_ctx *ctx, const char *name, float *dst_dev, size_t *n, vo
     EDV_CHECK(it != ctx->stages.end(), std::string("stage not available (capture off or unknown): ") + name);
     *n = it->second.second;
     if (dst_dev) return copy_f32(it->second.first, dst_dev, (long long)it->second.second, (hipStream_t)stream);
+    return 0;
+}
+
+int edv_profile_enable(edv_ctx *ctx, uint32_t class_mask) {
+    EDV_CHECK(ctx, "null context");
+    EDV_CHECK(class_mask < (1u << KC_COUNT), "unknown kernel class in mask");
+    ctx->prof_mask = class_mask;
+    for (auto &p : ctx->prof) p.used = 0;
+    return 0;
+}
+
+int edv_profile_read(edv_ctx *ctx, int32_t kernel_class, int32_t *launches, double *total_ms) {
+    EDV_CHECK(ctx && launches && total_ms, "null argument");
+    EDV_CHECK(kernel_class >= 0 && kernel_class < KC_COUNT, "unknown kernel class");
+    EvPool &p = ctx->prof[kernel_class];
+    double sum = 0.0;
+    for (size_t i = 0; i < p.used; ++i) {
+        EDV_HIP(hipEventSynchronize(p.ev[i].second));
+        float ms = 0.f;
+        EDV_HIP(hipEventElapsedTime(&ms, p.ev[i].first, p.ev[i].second));
+        sum += ms;
+    }
+    *launches = (int32_t)p.used;
+    *total_ms = sum;
+    p.used = 0;
     return 0;
 }
 

@@ -15,6 +15,8 @@
 // A[l&31][l>>5]).  Instead of two ds_read_b32 per instruction, lane-half h reads the float4
 // k = 8q+4h .. 8q+4h+3 of its row once and feeds element e to MFMA (q,e); A and W use the same
 // permutation of k, so the sum over k is unchanged, and LDS traffic drops to one b128 per 4 MFMAs.
+#include <cstdlib>
+
 #include "ops.hpp"
 
 namespace edv {
@@ -221,13 +223,20 @@ int launch_tile(const GemmDesc &d, hipStream_t st) {
 
 // 0: 128x128, 1: 128x64, 2: 128x32, 3: 64x64
 int pick_tile(const GemmDesc &d) {
+    static const int forced = [] {
+        const char *e = getenv("EDV_GEMM_TILE");  // debug override for tile sweeps: 0..3
+        return e ? atoi(e) : -1;
+    }();
+    if (forced >= 0 && forced <= 3) return forced;
     auto blocks = [&](int bm, int bn) { return ((d.M + bm - 1) / bm) * (long long)((d.N + bn - 1) / bn); };
     if (d.N <= 32) return 2;
-    // 128-wide tiles only when they add no column padding over 64-wide ones and still give the
-    // 256 CUs ~3 workgroups each; otherwise trade tile size for occupancy.
+    // Measured on MI355X (profiles/r01_gemm_tile_sweep.txt): the 128-wide tiles have the better main loop
+    // (73 % of the fp32 MFMA peak at large K) but at 3 resident workgroups per CU they lose up to 2x to
+    // tile-count quantisation when a problem has only a few tiles per CU (ViT-S, T=8: 774 tiles over 768
+    // slots); 64x64 tiles win there (qkv 58 -> 80 TF/s).  Big tiles only from ~10 tiles per CU upwards.
     const bool n128_free = ((d.N + 127) / 128) * 128 == ((d.N + 63) / 64) * 64;
-    if (n128_free && blocks(128, 128) >= 768) return 0;
-    if (blocks(128, 64) >= 512) return 1;
+    if (n128_free && blocks(128, 128) >= 2560) return 0;
+    if (blocks(128, 64) >= 2560) return 1;
     return 3;
 }
 

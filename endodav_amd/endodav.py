@@ -483,6 +483,20 @@ class endodav(nn.Module):
         nat = getattr(self, "_last", None)
         return int(_lib.load().edv_last_launch_count(C.c_void_p(nat.handle))) if nat else 0
 
+    def profile_enable(self, classes: Sequence[str]) -> None:
+        """Bracket every launch of the named kernel classes (``_lib.KERNEL_CLASSES``) with HIP events."""
+        nat = self._last
+        mask = 0
+        for c in classes:
+            mask |= 1 << _lib.KERNEL_CLASSES[c]
+        _lib.check(_lib.load().edv_profile_enable(C.c_void_p(nat.handle), mask), "edv_profile_enable")
+
+    def profile_read(self, cls: str) -> Tuple[int, float]:
+        """(launches, summed milliseconds) of one kernel class since the last read."""
+        n, ms = C.c_int32(), C.c_double()
+        _lib.check(_lib.load().edv_profile_read(C.c_void_p(self._last.handle), _lib.KERNEL_CLASSES[cls], C.byref(n), C.byref(ms)), "edv_profile_read")
+        return n.value, ms.value
+
     def device_bytes(self) -> int:
         nat = getattr(self, "_last", None)
         return int(_lib.load().edv_device_bytes(C.c_void_p(nat.handle))) if nat else 0

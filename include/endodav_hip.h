@@ -90,6 +90,12 @@ int edv_output_shape(const edv_ctx *ctx, int32_t scale, int32_t *h, int32_t *w);
 int edv_stage_copy(edv_ctx *ctx, const char *name, float *dst_dev, size_t *n, void *stream);
 /* Debug: when on, edv_forward also snapshots the in-place residual stream ("tokens", "block0"). */
 int edv_set_capture(edv_ctx *ctx, int on);
+/* Live per-kernel timing for bench.py's roofline: bracket every launch of the selected kernel classes with a
+ * HIP event pair on the launch stream.  Classes: 0 dense GEMM (Linear / 1x1 conv), 1 3x3 conv, 2 spatial
+ * attention, 3 temporal attention, 4 LayerNorm, 5 other.  edv_profile_read waits for the recorded events,
+ * returns the number of launches and their summed duration, and clears that class. */
+int edv_profile_enable(edv_ctx *ctx, uint32_t class_mask);
+int edv_profile_read(edv_ctx *ctx, int32_t kernel_class, int32_t *launches, double *total_ms);
 /* Bytes of device memory the context currently holds (packed weights + workspace). */
 size_t edv_device_bytes(const edv_ctx *ctx);
 /* Seconds spent in the dominant kernels are measured by the caller with HIP events; this

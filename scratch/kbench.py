@@ -1,0 +1,70 @@
+"""Kernel micro-benchmarks through the C ABI (diagnostic): TFLOP/s per shape."""
+import ctypes as C
+import sys
+
+import torch
+
+sys.path.insert(0, ".")
+from endodav_amd import _lib
+
+lib = _lib.load()
+dev = torch.device("cuda:0")
+st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e-3
+
+
+def gemm(M, N, K, act=0, res=False, label=""):
+    A = torch.randn(M, K, device=dev)
+    W = torch.randn(N, K, device=dev) * 0.05
+    Cm = torch.empty(M, N, device=dev)
+    b = torch.randn(N, device=dev)
+    R = torch.randn(M, N, device=dev) if res else None
+    t = timeit(lambda: _lib.check(lib.edv_gemm(A.data_ptr(), W.data_ptr(), Cm.data_ptr(), M, N, K, b.data_ptr(), act, None, _lib.ptr(R), st())))
+    print(f"gemm {label:10s} M={M:6d} N={N:5d} K={K:5d} act={act} res={int(res)}: {t*1e6:8.1f} us  {2*M*N*K/t/1e12:6.1f} TF", flush=True)
+
+
+def attn(F, N, heads):
+    qkv = torch.randn(F * N, 3 * heads * 64, device=dev)
+    o = torch.empty(F * N, heads * 64, device=dev)
+    t = timeit(lambda: _lib.check(lib.edv_attn_spatial(qkv.data_ptr(), o.data_ptr(), F, N, heads, st())))
+    print(f"attn F={F} N={N} heads={heads}: {t*1e6:8.1f} us  {4*N*N*64*heads*F/t/1e12:6.1f} TF", flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "sweep":
+    import os
+    print("EDV_GEMM_TILE", os.environ.get("EDV_GEMM_TILE"), "EDV_ATTN_WAVES", os.environ.get("EDV_ATTN_WAVES"))
+    for T in (8, 4):
+        M = T * 1370
+        gemm(M, 1152, 384, label=f"qkv T{T}")
+        gemm(M, 1536, 384, act=1, label=f"fc1 T{T}")
+        gemm(M, 384, 384, res=True, label=f"proj T{T}")
+        gemm(M, 384, 1536, res=True, label=f"fc2 T{T}")
+        attn(T, 1370, 6)
+elif __name__ == "__main__":
+    M = 8 * 1370
+    gemm(M, 1152, 384, label="qkv")
+    gemm(M, 1536, 384, act=1, label="fc1+gelu")
+    gemm(M, 1536, 384, act=0, label="fc1 noact")
+    gemm(M, 384, 384, res=True, label="proj")
+    gemm(M, 384, 1536, res=True, label="fc2")
+    gemm(M, 1536, 4096, label="bigK")
+    gemm(4096, 4096, 4096, label="4096^3")
+    gemm(8192, 8192, 1024, label="8k8k1k")
+    gemm(32 * 1370, 1152, 384, label="qkv T=32")
+    gemm(32 * 1370, 384, 1536, res=True, label="fc2 T=32")
+    attn(8, 1370, 6)
+    attn(32, 1370, 6)
+    attn(8, 4096, 6)
+    attn(2, 1370, 6)

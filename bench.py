@@ -81,11 +81,9 @@ def main():
     import torch.distributed as dist
 
     import endodav_amd
-    from endodav_amd import synth
+    from endodav_amd import parallel, synth
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
+    rank, world, local = parallel.env_rank_world()
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
@@ -95,9 +93,7 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    parallel.init("nccl", dev)
 
     kwargs = MODELS[args.encoder]
     T, S = args.T, args.image
@@ -108,8 +104,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
+        parallel.barrier()
 
     with torch.no_grad():
         for _ in range(max(args.warmup, 1)):
@@ -122,13 +117,9 @@ def main():
         for _ in range(args.steps):
             out = model(x)
         torch.cuda.synchronize(dev)
-        if world > 1:
-            dist.barrier()
+        parallel.barrier()
         dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt = parallel.max_over_ranks(dt, dev)
 
     roofline = None
     if not args.no_kernel_events:
@@ -142,6 +133,23 @@ def main():
                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
                         "launches": n, "avg_launch_ms": round(ms / n, 4), "flop_per_launch": flops,
                         "peak_dtype": "f32 MFMA (v_mfma_f32_32x32x2_f32), dense"}
+    # PCIe-inclusive variant (never `value`): pinned host clip -> HBM, forward, the four maps -> pinned host
+    pcie_value = None
+    if world == 1:
+        model.profile_enable([])
+        xh = x.cpu().pin_memory()
+        oh = [torch.empty_like(v, device="cpu").pin_memory() for v in out.values()]
+        with torch.no_grad():
+            torch.cuda.synchronize(dev)
+            n_p = max(args.steps // 2, 1)
+            t1 = time.perf_counter()
+            for _ in range(n_p):
+                xd = xh.to(dev, non_blocking=True)
+                o = model(xd)
+                for h, v in zip(oh, o.values()):
+                    h.copy_(v, non_blocking=True)
+            torch.cuda.synchronize(dev)
+            pcie_value = T * n_p / (time.perf_counter() - t1)
     finite = bool(torch.isfinite(out[("disp", 0)]).all().item())
     if rank == 0:
         frames = world * T * args.steps
@@ -158,6 +166,7 @@ def main():
             "model_tflop_per_clip": round(GFLOP_PER_FRAME[args.encoder] * T / 1e3 * (S / 518.0) ** 2, 4),
             "model_tflops": round(GFLOP_PER_FRAME[args.encoder] * (S / 518.0) ** 2 * value / 1e3, 2),
             "launches_per_step": model.launch_count(), "device_mem_mb": round(model.device_bytes() / 2 ** 20, 1), "output_finite": finite,
+            "pcie_inclusive_value": None if pcie_value is None else round(pcie_value, 2),
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -166,7 +175,7 @@ def main():
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
     if world > 1:
-        dist.barrier()
+        parallel.barrier()
         dist.destroy_process_group()
 
 

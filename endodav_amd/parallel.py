@@ -1,0 +1,72 @@
+"""Clip sharding across GPUs: one process per GPU, no data-path collective.
+
+``forward`` never mixes clips (the encoder treats B*T as a flat batch and the motion modules attend
+within a clip only: dpt_pyramid.py:71-74, motion_module.py:232), and the windows of a long video depend on
+each other only through *input* key frames (endodav.py:198-199), so inference partitions over independent
+units.  The only communication is the bookkeeping around a timed region (barrier, MAX of elapsed time) and
+the final gather of results to rank 0 — RCCL on GPUs (backend "nccl"), gloo in the CPU tests.
+"""
+from __future__ import annotations
+
+import os
+from typing import Any, List, Optional, Sequence
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init(backend: str, device: Optional[torch.device] = None) -> None:
+    """Join the default process group described by RANK / WORLD_SIZE / MASTER_* (no-op for one process)."""
+    rank, world, _ = env_rank_world()
+    if world == 1 or dist.is_initialized():
+        return
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    kwargs = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+    dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+
+
+def clip_shard(n_units: int, rank: int, world: int) -> List[int]:
+    """Round-robin assignment of independent units (clips / windows) to ranks."""
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world {world}")
+    return list(range(rank, n_units, world))
+
+
+def barrier() -> None:
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float:
+    """MAX-reduction of a host scalar (the elapsed time of a timed region)."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return float(value)
+    t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_to_rank0(obj: Any) -> Optional[List[Any]]:
+    """Collect one picklable object per rank on rank 0 (per-clip numpy results); None elsewhere."""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return [obj]
+    out = [None] * dist.get_world_size() if dist.get_rank() == 0 else None
+    dist.gather_object(obj, out, dst=0)
+    return out
+
+
+def merge_shards(shards: Sequence[Sequence[Any]], n_units: int) -> List[Any]:
+    """Inverse of ``clip_shard``: interleave the per-rank result lists back into unit order."""
+    world = len(shards)
+    out: List[Any] = [None] * n_units
+    for r, items in enumerate(shards):
+        idx = clip_shard(n_units, r, world)
+        if len(items) != len(idx):
+            raise ValueError(f"rank {r} returned {len(items)} results for {len(idx)} units")
+        for i, v in zip(idx, items):
+            out[i] = v
+    return out

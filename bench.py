@@ -49,6 +49,20 @@ def parse():
     return ap.parse_args()
 
 
+def measured_traffic(encoder, T, image):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (collected in
+    their own runs, FETCH_SIZE doubled as the gfx950 guide prescribes); None when no pass matches this workload."""
+    path = os.path.join(ROOT, "profiles", "r01_attn_traffic.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)
+    except OSError:
+        return None
+    if rec.get("config") == {"encoder": encoder, "T": T, "image": image}:
+        return rec["traffic_bytes_per_launch"]
+    return None
+
+
 def cpu_baseline(kwargs, T, image, threads):
     """Oracle on the host cores: 1 warm-up clip + timed clips until ~20 s or 3 clips."""
     import torch
@@ -130,7 +144,9 @@ def main():
         if n > 0 and ms > 0:
             achieved = flops / (ms / n * 1e-3) / 1e12
             roofline = {"kernel": "attn_spatial_kernel", "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(args.encoder, T, S),
+                        "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_attn_traffic.json)",
+                        "algorithmic_bytes_per_launch": 4.0 * ntok * T * heads * 64 * 4,
                         "launches": n, "avg_launch_ms": round(ms / n, 4), "flop_per_launch": flops,
                         "peak_dtype": "f32 MFMA (v_mfma_f32_32x32x2_f32), dense"}
     # PCIe-inclusive variant (never `value`): pinned host clip -> HBM, forward, the four maps -> pinned host

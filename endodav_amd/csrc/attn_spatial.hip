@@ -41,11 +41,21 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_kernel(const float *__re
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int head = blockIdx.y, frame = blockIdx.z;
+    // XCD-aware block -> (frame, head, query tile) map.  Workgroups b and b+8 share an XCD and its L2; the query
+    // tiles of one (frame, head) all sweep the same K/V, so hand each XCD a contiguous run of logical tiles
+    // (bijective for any grid size).  Measured: L2->fabric reads per launch 290 MB -> see profiles/.
+    const int nq = (N + QB - 1) / QB;
+    int bid = blockIdx.x;
+    {
+        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, x = bid & 7, loc = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+    }
+    const int qt = bid % nq, fh = bid / nq;
+    const int head = fh % heads, frame = fh / heads;
     const int D = heads * HD, D3 = 3 * D;
     const float *base = qkv + (long long)frame * N * D3 + head * HD;
 
-    const int qi = blockIdx.x * QB + wave * 32 + l31;
+    const int qi = qt * QB + wave * 32 + l31;
     const int qrow = qi < N ? qi : N - 1;
 
     // Q fragment in permuted-k order: element e of qf[qq] is d = 8*qq + 4*lh + e
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_kernel(const float *__re
 int attn_spatial(const float *qkv, float *out, int F, int N, int heads, hipStream_t st) {
     EDV_CHECK(qkv && out, "null operand");
     EDV_CHECK(F > 0 && N > 0 && heads > 0, "empty problem");
-    EDV_CHECK(F <= 65535 && heads <= 65535, "grid limits");
+    EDV_CHECK((long long)F * heads * ((N + 31) / 32) < (1ll << 31), "grid limits");
     EDV_CHECK(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 16 == 0), "16-byte alignment");
     // 4 waves (128 queries) per workgroup share each staged K/V tile.  The 2- and 1-wave variants give a finer
     // grid but cost registers (195 / 256 VGPRs) and measured slower on every shape tried (T=8: 79.9 vs 78.6 vs
@@ -178,7 +188,7 @@ int attn_spatial(const float *qkv, float *out, int F, int N, int heads, hipStrea
     }();
     int nw = N > 64 ? 4 : (N > 32 ? 2 : 1);
     if (forced == 1 || forced == 2 || forced == 4) nw = forced;
-    dim3 grid((N + nw * 32 - 1) / (nw * 32), heads, F);
+    dim3 grid((unsigned)((long long)((N + nw * 32 - 1) / (nw * 32)) * heads * F));
     if (nw == 4)
         hipLaunchKernelGGL(attn_spatial_kernel<4>, grid, dim3(256), 0, st, qkv, out, N, heads);
     else if (nw == 2)

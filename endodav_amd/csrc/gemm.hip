@@ -6,9 +6,9 @@
 //   ConvTranspose2d k=s dpt.py:71-82 (as GEMM + pixel-shuffle store)
 //   patch-embed conv    patch_embed.py:65,75 (after im2col by the patchify kernel)
 //
-// Tiling: workgroup = 256 threads = 4 waves, tile BM x BN x 32.  A and W tiles are staged
-// global -> VGPR -> LDS (loads of tile k+1 are issued before the MFMAs of tile k, written
-// after the barrier: the T14 split of the CDNA guide).  LDS rows are padded to 36 floats, which
+// Tiling: workgroup = 256 threads = 4 waves, tile BM x BN x 32, two LDS stages.  A and W tiles are staged
+// global -> VGPR -> LDS: the loads of tile k+2 are issued and tile k+1 is written to the other stage in the
+// middle of tile k's MFMA stream (the T14 split of the CDNA guide), so there is ONE barrier per k-tile.  LDS rows are padded to 36 floats, which
 // makes the ds_read_b128 fragment reads conflict-free (36r mod 64 is a bijection on r mod 16).
 //
 // K-order trick: the f32 MFMA takes ONE k per lane-half per instruction (lane l supplies
@@ -42,9 +42,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc g) {
     constexpr int RA = BM / 32, RB = BN / 32;  // float4 loads per thread per tile
     static_assert(WGM * WGN == 4 && FM >= 1 && FN >= 1, "4 waves");
 
-    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LS];
-    float *sA = smem;
-    float *sB = smem + BM * LS;
+    // two LDS stages: tile k+1 is written while tile k is being multiplied -> one barrier per k-tile
+    constexpr int STAGE = (BM + BN) * LS;
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -139,30 +139,46 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nkt = (g.K + BK - 1) / BK;
-    load_tile(0);
-    for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();  // previous tile's fragment reads are done
+    auto stage_store = [&](int buf) {
+        float *sA = smem + buf * STAGE;
+        float *sB = sA + BM * LS;
 #pragma unroll
         for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4 *>(&sA[(r0 + 32 * i) * LS + c * 4]) = ra[i];
 #pragma unroll
         for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4 *>(&sB[(r0 + 32 * i) * LS + c * 4]) = rb[i];
-        __syncthreads();
-        if (kt + 1 < nkt) load_tile(kt + 1);  // in flight under the MFMAs below
+    };
+    auto mfma_q = [&](int buf, int q) {
+        const float *sA = smem + buf * STAGE;
+        const float *sB = sA + BM * LS;
+        f32x4 fa[FM], fb[FN];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(&sA[(wm * WTM + i * 32 + l31) * LS + 8 * q + 4 * lh]);
+#pragma unroll
+        for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(&sB[(wn * WTN + j * 32 + l31) * LS + 8 * q + 4 * lh]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
+    };
 
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 fa[FM], fb[FN];
-#pragma unroll
-            for (int i = 0; i < FM; ++i) fa[i] = *reinterpret_cast<const f32x4 *>(&sA[(wm * WTM + i * 32 + l31) * LS + 8 * q + 4 * lh]);
-#pragma unroll
-            for (int j = 0; j < FN; ++j) fb[j] = *reinterpret_cast<const f32x4 *>(&sB[(wn * WTN + j * 32 + l31) * LS + 8 * q + 4 * lh]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
-        }
+    // prologue: tile 0 -> LDS stage 0, tile 1 -> registers
+    load_tile(0);
+    stage_store(0);
+    if (nkt > 1) load_tile(1);
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        mfma_q(cur, 0);
+        mfma_q(cur, 1);
+        // mid-stream: the other stage was last read in iteration kt-1 (barrier passed), so tile kt+1 can land now;
+        // its global loads were issued one whole iteration ago.  Then start fetching tile kt+2.
+        if (kt + 1 < nkt) stage_store(cur ^ 1);
+        if (kt + 2 < nkt) load_tile(kt + 2);
+        mfma_q(cur, 2);
+        mfma_q(cur, 3);
+        __syncthreads();
     }
 
     // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -228,15 +244,11 @@ int pick_tile(const GemmDesc &d) {
         return e ? atoi(e) : -1;
     }();
     if (forced >= 0 && forced <= 3) return forced;
-    auto blocks = [&](int bm, int bn) { return ((d.M + bm - 1) / bm) * (long long)((d.N + bn - 1) / bn); };
     if (d.N <= 32) return 2;
-    // Measured on MI355X (profiles/r01_gemm_tile_sweep.txt): the 128-wide tiles have the better main loop
-    // (73 % of the fp32 MFMA peak at large K) but at 3 resident workgroups per CU they lose up to 2x to
-    // tile-count quantisation when a problem has only a few tiles per CU (ViT-S, T=8: 774 tiles over 768
-    // slots); 64x64 tiles win there (qkv 58 -> 80 TF/s).  Big tiles only from ~10 tiles per CU upwards.
-    const bool n128_free = ((d.N + 127) / 128) * 128 == ((d.N + 63) / 64) * 64;
-    if (n128_free && blocks(128, 128) >= 2560) return 0;
-    if (blocks(128, 64) >= 2560) return 1;
+    // Measured on MI355X (profiles/r01_gemm_tile_sweep.txt): with two LDS stages the 64x64 tile (4 workgroups of
+    // 4 waves per CU, one 32x32 MFMA tile per wave) matches or beats the 128-wide tiles on every shape tried --
+    // 80 vs 58 TF/s on qkv at T=8 (774 big tiles over 512 resident slots quantise badly), 105 vs 71 at T=32,
+    // 114 vs 103 at 8192x8192x1024 -- so it is the default; the wide tiles stay reachable for experiments.
     return 3;
 }
 

@@ -1,0 +1,10 @@
+import ctypes as C, sys, torch
+sys.path.insert(0, ".")
+from endodav_amd import _lib
+lib = _lib.load(); dev = torch.device("cuda:0")
+st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+def gemm(M, N, K, reps=2, act=0):
+    A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) * 0.05; Cm = torch.empty(M, N, device=dev); b = torch.randn(N, device=dev)
+    for _ in range(reps): _lib.check(lib.edv_gemm(A.data_ptr(), W.data_ptr(), Cm.data_ptr(), M, N, K, b.data_ptr(), act, None, None, st()))
+    torch.cuda.synchronize()
+gemm(10960, 1152, 384); gemm(10960, 1536, 4096); gemm(8192, 8192, 1024)

@@ -11,7 +11,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libendodav_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 LORA_TYPES = {"none": 0, "lora": 1, "dvlora": 2, "ssb": 3, "dash": 4}
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_SIGMOID_NEG = 0, 1, 2, 3, 4
@@ -40,6 +40,8 @@ class EdvConfig(C.Structure):
         ("out_sigmoid", C.c_int32),
         ("temporal_lora", C.c_int32),
         ("dash_active", C.c_int32),
+        ("use_clstoken", C.c_int32),
+        ("residual_mask", C.c_uint32),
     ]
 
 

@@ -40,15 +40,17 @@ const char *get_error();
 constexpr int WAVE = 64;
 
 // Row remap: logical row m of a [frames * period] matrix lives at physical row
-//   (m / period) * stride + offset + (m % period).
+//   (m / period) * stride + offset + inner * (m % period).
 // period == 0 means identity.  Used to skip the cls row of each frame's token block, to
-// broadcast the position table over frames (stride 0) and to address sub-ranges in place.
+// broadcast the position table over frames (stride 0), to broadcast one row per frame over
+// that frame's rows (inner 0) and to address sub-ranges in place.
 struct RowMap {
     int period, stride, offset;
+    int inner = 1;
     __host__ __device__ inline long long operator()(long long m) const {
         if (period == 0) return m;
         long long f = m / period;
-        return f * stride + offset + (m - f * period);
+        return f * stride + offset + inner * (m - f * period);
     }
 };
 inline RowMap identity_map() { return RowMap{0, 0, 0}; }

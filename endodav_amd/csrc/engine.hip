@@ -239,6 +239,8 @@ struct Run {
             EDV_TRY(fold_linear(b + "fc1", true));
             EDV_TRY(fold_linear(b + "fc2", true));
         }
+        for (int i = 0; i < depth; ++i)
+            if (cfg.residual_mask & (1u << i)) EDV_TRY(pack_c3("pretrained.blocks." + std::to_string(i) + ".residual_.conv2"));
         const int *oc = cfg.out_channels;
         {  // ConvTranspose k=s -> GEMM weights
             const int ss[2] = {4, 2};
@@ -419,6 +421,44 @@ struct Run {
         return 0;
     }
 
+    // ---- ResBottleneckBlock on the patch tokens of encoder block i (block.py:146-150, layers/utils.py:90-153):
+    // 1x1 -> LN -> GELU -> 3x3 -> LN -> GELU -> 1x1 -> LN, added to the patch rows of the residual stream.
+    int res_bottleneck(int i, float *xt) {
+        // the reference reshapes to the Block's construction-time grid, input_size=(224,280) -> 16x20 (block.py:70-73)
+        EDV_CHECK(ph == 16 && pw == 20, "shape '[B, 16, 20, C]' is invalid for the patch tokens: residual blocks need image_shape (224, 280)");
+        const std::string p = "pretrained.blocks." + std::to_string(i) + ".residual_";
+        const int Cb = D / 8;
+        const long long MP = (long long)F * P0;
+        float *t1, *t2, *t3;
+        EDV_TRY(wsbuf("rb.t1", (size_t)MP * Cb, &t1));
+        EDV_TRY(wsbuf("rb.t2", (size_t)MP * Cb, &t2));
+        EDV_TRY(wsbuf("rb.t3", (size_t)MP * D, &t3));
+        const float *w, *nw, *nb;
+        EDV_TRY(param(p + ".conv1.weight", &w, 4));
+        {
+            GemmDesc g;
+            g.A = xt; g.lda = D; g.a_map = RowMap{P0, ntok, c0}; g.W = w; g.ldw = D; g.C = t1; g.ldc = Cb; g.M = MP; g.N = Cb; g.K = D;
+            c->launches++;
+            Bracket b_(c, KC_LINEAR, st);
+            EDV_TRY(gemm(g, st));
+        }
+        EDV_TRY(param(p + ".norm1.weight", &nw));
+        EDV_TRY(param(p + ".norm1.bias", &nb));
+        EDV_TRY(layernorm(t1, identity_map(), nw, nb, t2, identity_map(), MP, Cb, 1e-6f, nullptr, 0, 0, st, ACT_GELU));
+        EDV_TRY(packedw(p + ".conv2.weight", &w));
+        EDV_TRY(conv3(t2, ph, pw, Cb, w, nullptr, Cb, 1, t1, false));
+        EDV_TRY(param(p + ".norm2.weight", &nw));
+        EDV_TRY(param(p + ".norm2.bias", &nb));
+        EDV_TRY(layernorm(t1, identity_map(), nw, nb, t2, identity_map(), MP, Cb, 1e-6f, nullptr, 0, 0, st, ACT_GELU));
+        EDV_TRY(param(p + ".conv3.weight", &w, 4));
+        EDV_TRY(linear(t2, MP, Cb, w, D, nullptr, t3));
+        EDV_TRY(param(p + ".norm3.weight", &nw));
+        EDV_TRY(param(p + ".norm3.bias", &nb));
+        EDV_TRY(layernorm(t3, identity_map(), nw, nb, xt, RowMap{P0, ntok, c0}, MP, D, 1e-6f, nullptr, 0, 0, st, ACT_NONE, true));
+        c->launches += 3;
+        return 0;
+    }
+
     int forward(const float *x, int B_, int T_, int H, int W, float *const disp[4]) {
         B = B_; T = T_; F = B * T;
         ph = cfg.image_h / 14; pw = cfg.image_w / 14; P0 = ph * pw;
@@ -438,8 +478,10 @@ struct Run {
         EDV_TRY(wsbuf("qkv", (size_t)MT * 3 * D, &qkv));
         EDV_TRY(wsbuf("att", (size_t)MT * D, &att));
         EDV_TRY(wsbuf("hid", (size_t)MT * 4 * D, &hid));
-        float *tap[4];
+        float *tap[4], *tapcls[4] = {nullptr, nullptr, nullptr, nullptr};
         for (int j = 0; j < 4; ++j) EDV_TRY(wsbuf("tap" + std::to_string(j), (size_t)F * P0 * D, &tap[j]));
+        if (cfg.use_clstoken)
+            for (int j = 0; j < 4; ++j) EDV_TRY(wsbuf("tapcls" + std::to_string(j), (size_t)F * D, &tapcls[j]));
 
         const float *pos;
         EDV_TRY(pos_table(&pos));
@@ -490,11 +532,15 @@ struct Run {
             EDV_TRY(param(bp + ".mlp.fc2.bias", &b));
             EDV_TRY(param(bp + ".ls2.gamma", &gam));
             EDV_TRY(linear(hid, MT, 4 * D, w, D, b, xt, ACT_NONE, gam, xt));
+            if (cfg.residual_mask & (1u << i)) EDV_TRY(res_bottleneck(i, xt));
             if (i == 0) EDV_TRY(snapshot("block0", xt, (size_t)MT * D));
             if (tapj < 4 && i == cfg.taps[tapj]) {
                 // final norm on the tap, cls row dropped (vision_transformer.py:317-321)
                 EDV_TRY(ln(xt, RowMap{P0, ntok, c0}, "pretrained.norm", tap[tapj], (long long)F * P0, D, 1e-6f));
                 c->stages["tap" + std::to_string(tapj)] = {tap[tapj], (size_t)F * P0 * D};
+                // token 0 of every frame, normed: the cls token, or with include_cls_token=False the first patch
+                // ("not real cls tokens", vision_transformer.py:322-324)
+                if (cfg.use_clstoken) EDV_TRY(ln(xt, RowMap{1, ntok, 0}, "pretrained.norm", tapcls[tapj], F, D, 1e-6f));
                 ++tapj;
             }
         }
@@ -513,13 +559,40 @@ struct Run {
             for (int j = 1; j < 4; ++j) mx = oc[j] > mx ? oc[j] : mx;
             EDV_TRY(wsbuf("pj", (size_t)MP * mx, &pj));
         }
+        float *readout = nullptr, *fbias = nullptr;
+        if (cfg.use_clstoken) {
+            EDV_TRY(wsbuf("readout", (size_t)MP * D, &readout));
+            EDV_TRY(wsbuf("readout.fb", (size_t)F * D, &fbias));
+        }
         for (int j = 0; j < 4; ++j) {
             const std::string pp = "head.projects." + std::to_string(j);
             const float *w, *b;
+            const float *src = tap[j];
+            if (cfg.use_clstoken) {
+                // readout_projects[j] = GELU(Linear(2D -> D)) on cat(x, cls): W = [W1 | W2], so
+                // y = GELU(W1 x + (W2 cls + b)); the bracket is one [F, D] vector per frame (dpt_pyramid.py:54-57)
+                const std::string rp = "head.readout_projects." + std::to_string(j) + ".0";
+                const float *rw, *rbias;
+                EDV_TRY(param(rp + ".weight", &rw, 2));
+                EDV_TRY(param(rp + ".bias", &rbias));
+                GemmDesc g1;
+                g1.A = tapcls[j]; g1.lda = D; g1.W = rw + D; g1.ldw = 2 * D; g1.C = fbias; g1.ldc = D; g1.M = F; g1.N = D; g1.K = D; g1.bias = rbias;
+                EDV_TRY(gemm(g1, st));
+                GemmDesc g2;
+                g2.A = tap[j]; g2.lda = D; g2.W = rw; g2.ldw = 2 * D; g2.C = readout; g2.ldc = D; g2.M = MP; g2.N = D; g2.K = D;
+                g2.P1 = fbias; g2.ldp1 = D; g2.act = ACT_GELU;
+                g2.p1_map = RowMap{P0, 1, 0, 0};  // inner 0: one bias row per frame
+                EDV_TRY(gemm(g2, st));
+                c->launches += 2;
+                src = readout;
+                c->stages["tapcls" + std::to_string(j)] = {tapcls[j], (size_t)F * D};
+                c->stages["fbias"] = {fbias, (size_t)F * D};       // last level only (buffers are reused)
+                c->stages["readout"] = {readout, (size_t)MP * D};
+            }
             EDV_TRY(param(pp + ".weight", &w, 4));
             EDV_TRY(param(pp + ".bias", &b));
             float *dst = (j == 2) ? l3 : pj;
-            EDV_TRY(linear(tap[j], MP, D, w, oc[j], b, dst));
+            EDV_TRY(linear(src, MP, D, w, oc[j], b, dst));
             if (j < 2) {
                 const int s = j == 0 ? 4 : 2;
                 const std::string rp = "head.resize_layers." + std::to_string(j);
@@ -659,6 +732,8 @@ int edv_create(const edv_config *cfg, edv_ctx **out) {
     EDV_CHECK(cfg->out_channels[2] % 32 == 0 && cfg->out_channels[3] % 32 == 0, "out_channels[2:] must be multiples of 32");
     EDV_CHECK(cfg->features <= 1024 && cfg->out_channels[2] <= 1024 && cfg->out_channels[3] <= 1024, "temporal width > 1024 unsupported");
     EDV_CHECK(cfg->lora_type >= 0 && cfg->lora_type <= EDV_LORA_DASH, "lora_type");
+    EDV_CHECK(cfg->depth <= 32 && (cfg->depth == 32 || (cfg->residual_mask >> cfg->depth) == 0), "residual_mask names a block >= depth");
+    EDV_CHECK(cfg->residual_mask == 0 || (cfg->embed_dim / 8) % 4 == 0, "residual blocks need embed_dim / 8 to be a multiple of 4");
     for (int j = 0; j < 4; ++j) EDV_CHECK(cfg->taps[j] >= 0 && cfg->taps[j] < cfg->depth && (j == 0 || cfg->taps[j] > cfg->taps[j - 1]), "taps");
     *out = new edv_ctx();
     (*out)->cfg = *cfg;

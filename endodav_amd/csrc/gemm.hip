@@ -95,8 +95,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc g) {
         b_ptr[i] = (n < g.N) ? g.W + (long long)n * g.ldw : nullptr;
     }
 
-    f32x4 ra[RA], rb[RB];
-    auto load_tile = [&](int kt) {
+    // two register sets: tiles k+1 and k+2 are in flight while tile k is multiplied
+    f32x4 ra0[RA], rb0[RB], ra1[RA], rb1[RB];
+    auto load_tile = [&](int kt, f32x4(&ra)[RA], f32x4(&rb)[RB]) {
         const int k = kt * BK + c * 4;
         const bool kin = k < g.K;  // K % 4 == 0, so a chunk is wholly in or out
         if (LOADER == LOAD_DENSE) {
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nkt = (g.K + BK - 1) / BK;
-    auto stage_store = [&](int buf) {
+    auto stage_store = [&](int buf, const f32x4(&ra)[RA], const f32x4(&rb)[RB]) {
         float *sA = smem + buf * STAGE;
         float *sB = sA + BM * LS;
 #pragma unroll
@@ -163,21 +164,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc g) {
                 for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][e], fb[j][e], acc[i][j], 0, 0, 0);
     };
 
-    // prologue: tile 0 -> LDS stage 0, tile 1 -> registers
-    load_tile(0);
-    stage_store(0);
-    if (nkt > 1) load_tile(1);
+    // prologue: tile 0 -> LDS stage 0; tiles 1 and 2 -> register sets 0 and 1
+    load_tile(0, ra0, rb0);
+    stage_store(0, ra0, rb0);
+    if (nkt > 1) load_tile(1, ra0, rb0);
+    if (nkt > 2) load_tile(2, ra1, rb1);
     __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        mfma_q(cur, 0);
-        mfma_q(cur, 1);
-        // mid-stream: the other stage was last read in iteration kt-1 (barrier passed), so tile kt+1 can land now;
-        // its global loads were issued one whole iteration ago.  Then start fetching tile kt+2.
-        if (kt + 1 < nkt) stage_store(cur ^ 1);
-        if (kt + 2 < nkt) load_tile(kt + 2);
-        mfma_q(cur, 2);
-        mfma_q(cur, 3);
+    // Steady state, unrolled by two so that the register sets keep static names.  In iteration kt the other LDS
+    // stage was last read in iteration kt-1 (barrier passed), so tile kt+1 lands there mid-stream; its global loads
+    // were issued TWO iterations ago, which is what hides the L2/HBM latency behind only ~1k MFMA cycles per
+    // iteration on the 64x64 tile.  One barrier per k-tile.
+    for (int kt = 0; kt < nkt; kt += 2) {
+        mfma_q(0, 0);
+        mfma_q(0, 1);
+        if (kt + 1 < nkt) stage_store(1, ra0, rb0);
+        if (kt + 3 < nkt) load_tile(kt + 3, ra0, rb0);
+        mfma_q(0, 2);
+        mfma_q(0, 3);
+        __syncthreads();
+        if (kt + 1 >= nkt) break;
+        mfma_q(1, 0);
+        mfma_q(1, 1);
+        if (kt + 2 < nkt) stage_store(0, ra1, rb1);
+        if (kt + 4 < nkt) load_tile(kt + 4, ra1, rb1);
+        mfma_q(1, 2);
+        mfma_q(1, 3);
         __syncthreads();
     }
 
@@ -201,7 +212,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc g) {
             for (int r = 0; r < 16; ++r) {
                 const long long m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m >= g.M) continue;
-                float v = apply_act(acc[i][j][r] + bias, g.act) * gam;
+                float pre = acc[i][j][r] + bias;
+                if (g.P1) pre += g.P1[g.p1_map(m) * g.ldp1 + n];
+                float v = apply_act(pre, g.act) * gam;
                 if (STORE == STORE_ROWS) {
                     const long long crow = g.c_map(m);
                     if (g.R1) v += g.R1[g.r1_map(m) * g.ldr1 + n];
@@ -268,7 +281,7 @@ int gemm(const GemmDesc &d, hipStream_t st) {
     }
     if (d.store == STORE_SHUFFLE) {
         EDV_CHECK(d.ps_s > 0 && d.N == d.ps_s * d.ps_s * d.ps_C, "pixel-shuffle N");
-        EDV_CHECK(d.R1 == nullptr && d.R2 == nullptr, "pixel-shuffle store takes no residual");
+        EDV_CHECK(d.R1 == nullptr && d.R2 == nullptr && d.P1 == nullptr, "pixel-shuffle store takes no residual");
     }
     EDV_CHECK(((uintptr_t)d.A % 16 == 0) && ((uintptr_t)d.W % 16 == 0), "A/W must be 16-byte aligned");
     switch (pick_tile(d)) {

@@ -13,8 +13,9 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int LN_MAXV = 4;  // float4 per lane -> dim <= 1024
 
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, RowMap in_map, const float *__restrict__ w,
-                                                         const float *__restrict__ b, float *__restrict__ y, RowMap out_map, long long rows,
-                                                         int dim, float eps, const float *__restrict__ pe, int rows_per_frame, int T) {
+                                                         const float *__restrict__ b, float *y, RowMap out_map, long long rows,
+                                                         int dim, float eps, const float *__restrict__ pe, int rows_per_frame, int T, int act,
+                                                         int accumulate) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
@@ -53,6 +54,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict_
             const f32x4 be = *reinterpret_cast<const f32x4 *>(b + 4 * c);
             f32x4 o = (v[i] - mean) * rstd * g + be;
             if (per) o += *reinterpret_cast<const f32x4 *>(per + 4 * c);
+            if (act == ACT_GELU) o = f32x4{gelu_erf(o.x), gelu_erf(o.y), gelu_erf(o.z), gelu_erf(o.w)};
+            if (accumulate) o += *reinterpret_cast<const f32x4 *>(yr + 4 * c);
             *reinterpret_cast<f32x4 *>(yr + 4 * c) = o;
         }
     }
@@ -117,15 +120,16 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float *__res
 }  // namespace
 
 int layernorm(const float *x, RowMap in_map, const float *w, const float *b, float *y, RowMap out_map, long long rows, int dim, float eps,
-              const float *pe, int rows_per_frame, int T, hipStream_t st) {
+              const float *pe, int rows_per_frame, int T, hipStream_t st, int act, bool accumulate) {
     EDV_CHECK(x && w && b && y, "null operand");
+    EDV_CHECK(act == ACT_NONE || act == ACT_GELU, "layernorm act must be none or gelu");
     EDV_CHECK(rows > 0, "empty problem");
     EDV_CHECK(dim % 4 == 0 && dim <= 256 * LN_MAXV, "dim must be a multiple of 4 and <= 1024");
     EDV_CHECK(!pe || (rows_per_frame > 0 && T > 0), "pe needs rows_per_frame and T");
     const long long blocks = (rows + 3) / 4;
     EDV_CHECK(blocks < (1ll << 31), "grid");
     hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, in_map, w, b, y, out_map, rows, dim, eps, pe,
-                       rows_per_frame > 0 ? rows_per_frame : 1, T > 0 ? T : 1);
+                       rows_per_frame > 0 ? rows_per_frame : 1, T > 0 ? T : 1, act, accumulate ? 1 : 0);
     EDV_LAUNCH_OK();
     return 0;
 }

@@ -7,7 +7,7 @@ namespace edv {
 
 // ------------------------------------------------------------------------------------------
 // GEMM family (gemm.hip):  C = epilogue(Aop · Wᵀ),  W [N,K] row-major (torch Linear layout).
-//   epilogue:  v = acc + bias[n];  v = act(v);  v *= gamma[n];  v += R1[r1_map(m), n];  v += R2[c_row, n]
+//   epilogue:  v = acc + bias[n] + P1[p1_map(m), n];  v = act(v);  v *= gamma[n];  v += R1[r1_map(m), n];  v += R2[c_row, n]
 // A operand:  LOAD_DENSE  A[a_map(m), k]
 //             LOAD_CONV3  implicit im2col of a channels-last image x[F,H,W,Cin], k = (ky*3+kx)*Cin+ci,
 //                         zero padding 1, stride cs, optional ReLU on the loaded value
@@ -38,6 +38,9 @@ struct GemmDesc {
     RowMap r1_map{0, 0, 0};
     const float *R2 = nullptr;
     int ldr2 = 0;
+    const float *P1 = nullptr;  // pre-activation addend (per-frame readout bias of use_clstoken, dpt_pyramid.py:54-57)
+    int ldp1 = 0;
+    RowMap p1_map{0, 0, 0};
     int loader = LOAD_DENSE;
     int cH = 0, cW = 0, cC = 0, cOH = 0, cOW = 0, cS = 1, pre_relu = 0;
     int store = STORE_ROWS;
@@ -57,9 +60,9 @@ int geglu(const float *x, float *y, long long M, int inner, hipStream_t st);
 // ------------------------------------------------------------------------------------------
 // norms (norms.hip)
 // ------------------------------------------------------------------------------------------
-// y[out_map(m)] = LN(x[in_map(m)]) * w + b (+ pe[(m / rows_per_frame) % T])
+// y[out_map(m)] (+)= act(LN(x[in_map(m)]) * w + b (+ pe[(m / rows_per_frame) % T]));  act: ACT_NONE / ACT_GELU
 int layernorm(const float *x, RowMap in_map, const float *w, const float *b, float *y, RowMap out_map, long long rows, int dim,
-              float eps, const float *pe, int rows_per_frame, int T, hipStream_t st);
+              float eps, const float *pe, int rows_per_frame, int T, hipStream_t st, int act = ACT_NONE, bool accumulate = false);
 int groupnorm(const float *x, const float *w, const float *b, float *y, float *stats, int F, int P, int C, int groups, float eps,
               hipStream_t st);
 

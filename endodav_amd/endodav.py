@@ -93,6 +93,8 @@ class SSBLinear(nn.Linear):
 class DashLinear(LoRALinear):
     """mylora/layers.py:487-585: LoRA + an 8-direction SVD term switched on after 100 calls."""
 
+    WARMUP = 100
+
     def __init__(self, in_features, out_features, r=0, lora_alpha=1):
         super().__init__(in_features, out_features, r, lora_alpha)
         self.index = 8
@@ -136,8 +138,31 @@ class _Mlp(_Holder):  # layers/mlp.py:16-31
         self.fc2 = nn.Linear(4 * dim, dim)
 
 
+class _CFLayerNorm(_Holder):  # channels-first LayerNorm of layers/utils.py:155-179 (weight, bias only)
+    def __init__(self, n):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(n))
+        self.bias = nn.Parameter(torch.zeros(n))
+        self.eps = 1e-6
+
+
+class _ResBottleneck(_Holder):  # layers/utils.py:90-153: 1x1 -> LN -> GELU -> 3x3 -> LN -> GELU -> 1x1 -> LN
+    def __init__(self, dim):
+        super().__init__()
+        b = dim // 8
+        self.conv1 = nn.Conv2d(dim, b, 1, bias=False)
+        self.norm1 = _CFLayerNorm(b)
+        self.conv2 = nn.Conv2d(b, b, 3, padding=1, bias=False)
+        self.norm2 = _CFLayerNorm(b)
+        self.conv3 = nn.Conv2d(b, dim, 1, bias=False)
+        self.norm3 = _CFLayerNorm(dim)
+        for conv in (self.conv1, self.conv2, self.conv3):  # fvcore c2_msra_fill
+            nn.init.kaiming_normal_(conv.weight, mode="fan_out", nonlinearity="relu")
+        nn.init.zeros_(self.norm3.weight)  # "zero init last norm layer" (:149-151)
+
+
 class _Block(_Holder):  # layers/block.py:42-109
-    def __init__(self, dim, heads):
+    def __init__(self, dim, heads, use_residual_block=False):
         super().__init__()
         self.norm1 = nn.LayerNorm(dim, eps=1e-6)
         self.attn = _Attn(dim, heads)
@@ -145,6 +170,9 @@ class _Block(_Holder):  # layers/block.py:42-109
         self.norm2 = nn.LayerNorm(dim, eps=1e-6)
         self.mlp = _Mlp(dim)
         self.ls2 = _Gamma(dim)
+        self.use_residual_block = use_residual_block
+        if use_residual_block:
+            self.residual_ = _ResBottleneck(dim)
 
 
 class _PatchEmbed(_Holder):  # layers/patch_embed.py:38-66
@@ -156,7 +184,7 @@ class _PatchEmbed(_Holder):  # layers/patch_embed.py:38-66
 class _Backbone(_Holder):
     """Parameter tree of DinoVisionTransformer (vision_transformer.py:43-184)."""
 
-    def __init__(self, dim, depth, heads, img_size):
+    def __init__(self, dim, depth, heads, img_size, residual_block_indexes=()):
         super().__init__()
         self.embed_dim = self.num_features = dim
         self.n_blocks, self.num_heads, self.patch_size = depth, heads, PATCH
@@ -164,7 +192,7 @@ class _Backbone(_Holder):
         self.patch_embed = _PatchEmbed(dim)
         self.cls_token = nn.Parameter(torch.zeros(1, 1, dim))
         self.pos_embed = nn.Parameter(torch.zeros(1, n_patches + 1, dim))
-        self.blocks = nn.ModuleList([_Block(dim, heads) for _ in range(depth)])
+        self.blocks = nn.ModuleList([_Block(dim, heads, i in residual_block_indexes) for i in range(depth)])
         self.norm = nn.LayerNorm(dim, eps=1e-6)
         self.mask_token = nn.Parameter(torch.zeros(1, dim))
         nn.init.trunc_normal_(self.pos_embed, std=0.02)  # vision_transformer.py:180-184
@@ -263,9 +291,10 @@ class HeadDepth(_Holder):  # endodav/layers.py:206-221
 class _Head(_Holder):
     """Parameter tree of DPTHeadPyramid (dpt.py:47-124, dpt_temporal.py:22-51, dpt_pyramid.py:22-49)."""
 
-    def __init__(self, in_channels, features, out_channels, num_frames, disable_conv_head):
+    def __init__(self, in_channels, features, out_channels, num_frames, disable_conv_head, use_clstoken=False):
         super().__init__()
         oc = list(out_channels)
+        self.use_clstoken = use_clstoken
         self.projects = nn.ModuleList([nn.Conv2d(in_channels, c, 1, 1, 0) for c in oc])
         self.resize_layers = nn.ModuleList([
             nn.ConvTranspose2d(oc[0], oc[0], 4, 4, 0),
@@ -273,6 +302,8 @@ class _Head(_Holder):
             nn.Identity(),
             nn.Conv2d(oc[3], oc[3], 3, 2, 1),
         ])
+        if use_clstoken:  # dpt.py:92-98
+            self.readout_projects = nn.ModuleList([nn.Sequential(nn.Linear(2 * in_channels, in_channels), nn.GELU()) for _ in oc])
         s = nn.Module()
         for j in range(4):
             setattr(s, f"layer{j + 1}_rn", nn.Conv2d(oc[j], features, 3, 1, 1, bias=False))
@@ -335,12 +366,9 @@ class endodav(nn.Module):
         dim, depth, heads, img_size, taps = ENCODERS[encoder]  # KeyError for an unknown encoder, like endodav.py:92
         if use_bn:
             raise NotImplementedError("use_bn=True (BatchNorm in the fusion blocks) is not built; no reference caller sets it")
-        if use_clstoken:
-            raise NotImplementedError("use_clstoken=True (readout projections) is not built; no reference caller sets it")
         if pe != "ape":
             raise NotImplementedError("only pe='ape' (the reference default) is built")
-        if list(residual_block_indexes):
-            raise NotImplementedError("residual_block_indexes != [] is not built yet (every endodav script passes --disable_residual_block)")
+        residual_block_indexes = [int(i) for i in residual_block_indexes]
         self.encoder = encoder
         self.intermediate_layer_idx = {encoder: list(taps)}
         self.image_shape = tuple(image_shape)
@@ -351,9 +379,12 @@ class endodav(nn.Module):
         self.inv_sigmoid, self.out_sigmoid = inv_sigmoid, out_sigmoid
         self.temporal_lora, self.disable_conv_head = temporal_lora, disable_conv_head
         self.features, self.out_channels = features, list(out_channels)
+        self.use_clstoken = bool(use_clstoken)
+        self.residual_block_indexes = [i for i in residual_block_indexes if 0 <= i < depth]
+        self._dash_calls = 0  # DashLinear.FLAG of the reference, one shared count (every Dash layer sees every forward)
 
-        self.pretrained = _Backbone(dim, depth, heads, img_size)
-        self.head = _Head(dim, features, out_channels, num_frames, disable_conv_head)
+        self.pretrained = _Backbone(dim, depth, heads, img_size, self.residual_block_indexes)
+        self.head = _Head(dim, features, out_channels, num_frames, disable_conv_head, self.use_clstoken)
 
         if lora_type != "none":  # endodav.py:102-137
             for blk in self.pretrained.blocks:
@@ -397,12 +428,17 @@ class endodav(nn.Module):
         cfg.conv_head = int(not self.disable_conv_head)
         cfg.inv_sigmoid, cfg.out_sigmoid = int(bool(self.inv_sigmoid)), int(bool(self.out_sigmoid))
         cfg.temporal_lora = int(bool(self.temporal_lora))
-        cfg.dash_active = 0
+        cfg.dash_active = int(self.lora_type == "dash" and self._dash_calls > DashLinear.WARMUP)
+        cfg.use_clstoken = int(self.use_clstoken)
+        mask = 0
+        for i in self.residual_block_indexes:
+            mask |= 1 << i
+        cfg.residual_mask = mask
         return cfg
 
     def _ensure_ctx(self, device: torch.device) -> int:
         lib = _lib.load()
-        key = str(device)
+        key = str(device) + ("+dash" if (self.lora_type == "dash" and self._dash_calls > DashLinear.WARMUP) else "")
         nat = self._native.get(key)
         if nat is None:
             h = C.c_void_p()
@@ -425,6 +461,35 @@ class endodav(nn.Module):
             _lib.check(lib.edv_prepare(C.c_void_p(nat.handle), C.c_void_p(_lib.stream_ptr(device))), "edv_prepare")
             nat.sig = sig
         return nat.handle
+
+    def _dash_layers(self):
+        return [m for m in self.modules() if isinstance(m, DashLinear)]
+
+    @torch.no_grad()
+    def _dash_step(self) -> None:
+        """DashLinear's call counter (mylora/layers.py:558-583).  Calls 1..100 are plain LoRA; on call 101 every layer
+        picks the 8 singular directions of W whose singular values the LoRA update changes most (relative change
+        |diag(Uᵀ ΔW V)| / σ), stores them in weight_u_top / weight_vt_top and frees lora_index; from then on the engine
+        folds U_top diag(lora_index) Vt_top into W as well.  The SVD is a one-off host-side selection step."""
+        self._dash_calls += 1
+        for m in self._dash_layers():
+            m.FLAG = self._dash_calls
+        if self._dash_calls == 1:
+            for m in self._dash_layers():
+                m.lora_index.requires_grad = m.weight_u_top.requires_grad = m.weight_vt_top.requires_grad = False
+        if self._dash_calls == DashLinear.WARMUP + 1:
+            for m in self._dash_layers():
+                # on the host CPU: the ranking below is a discrete choice, and LAPACK's SVD is what the reference
+                # goldens were captured with (rocSOLVER's rounding picks different directions on near-ties)
+                dev = m.weight.device
+                w = m.weight.detach().float().cpu()
+                delta = (m.lora_B.detach().float().cpu() @ m.lora_A.detach().float().cpu()) * m.scaling
+                u, sig, vt = torch.linalg.svd(w, full_matrices=False)
+                dsig = torch.diag(u.T @ delta @ vt.T)
+                top = torch.topk(dsig.abs() / sig.abs(), m.index).indices
+                m.weight_u_top.data = u[:, top].contiguous().to(dev)
+                m.weight_vt_top.data = vt[top, :].contiguous().to(dev)
+                m.lora_index.requires_grad = True
 
     def output_shapes(self) -> List[Tuple[int, int]]:
         ph, pw = self.image_shape[0] // PATCH, self.image_shape[1] // PATCH
@@ -454,6 +519,8 @@ class endodav(nn.Module):
         if T > self.num_frames:  # motion_module.py:197: pe[:, :T] cannot broadcast
             raise RuntimeError(f"The size of tensor a ({T}) must match the size of tensor b ({self.num_frames}) at non-singleton dimension 1")
         x = x.detach().contiguous().float()
+        if self.lora_type == "dash":
+            self._dash_step()
         with torch.cuda.device(x.device):
             ctx = self._ensure_ctx(x.device)
             outs = [torch.empty((B * T, 1, h, w), device=x.device, dtype=torch.float32) for (h, w) in self.output_shapes()]

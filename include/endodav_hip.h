@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EDV_ABI_VERSION 1
+#define EDV_ABI_VERSION 2
 
 enum edv_lora_type { EDV_LORA_NONE = 0, EDV_LORA_LORA = 1, EDV_LORA_DVLORA = 2, EDV_LORA_SSB = 3, EDV_LORA_DASH = 4 };
 
@@ -57,6 +57,9 @@ typedef struct edv_config {
     int32_t out_sigmoid;        /* dpt_pyramid.py:97-101 */
     int32_t temporal_lora;      /* endodav.py:119-137 */
     int32_t dash_active;        /* DashLinear past warm-up: add U_top diag(idx) Vt_top */
+    int32_t use_clstoken;       /* DPT readout projections, dpt_pyramid.py:54-57 */
+    uint32_t residual_mask;     /* bit i set: encoder block i carries a ResBottleneckBlock (block.py:146-150);
+                                 * the reference hard-wires its grid to 16x20 patches = image_shape (224, 280) */
 } edv_config;
 
 typedef struct edv_ctx edv_ctx;

@@ -25,6 +25,13 @@ CASES = {
     "micro_t1": (dict(VITS_SMALL_HEAD, image_shape=(42, 56), lora_type="dvlora", disable_conv_head=True), (1, 1, 42, 56), "uniform", "full"),
     "micro_t32": (dict(VITS_SMALL_HEAD, image_shape=(42, 42), lora_type="dvlora", disable_conv_head=True), (1, 32, 42, 42), "tissue", "full"),
     "micro_vitl": (dict(VITL_SMALL_HEAD, image_shape=(42, 56), lora_type="dvlora", disable_conv_head=True), (1, 2, 42, 56), "uniform", "full"),
+    # --- options no reference script sets, still part of the constructor surface --------------------------
+    "micro_clstoken": (dict(VITS_SMALL_HEAD, image_shape=(42, 56), lora_type="dvlora", disable_conv_head=True, use_clstoken=True), (1, 2, 42, 56), "uniform", "full"),
+    "micro_clstoken_nocls": (dict(VITS_SMALL_HEAD, image_shape=(42, 56), lora_type="lora", use_clstoken=True, include_cls_token=False), (1, 2, 42, 56), "uniform", "full"),
+    "micro_dash": (dict(VITS_SMALL_HEAD, image_shape=(42, 56), lora_type="dash", disable_conv_head=True), (1, 2, 42, 56), "uniform", "full"),
+    "micro_dash_active": (dict(VITS_SMALL_HEAD, image_shape=(42, 56), lora_type="dash", disable_conv_head=True), (1, 2, 42, 56), "uniform", "full"),
+    # residual bottleneck blocks: the reference hard-wires their grid to 16x20 patches, i.e. image_shape (224, 280)
+    "resblock_224x280": (dict(VITS_SMALL_HEAD, image_shape=(224, 280), lora_type="dvlora", residual_block_indexes=[2, 5, 8, 11]), (1, 2, 224, 280), "tissue", "strided"),
     # --- reference default geometry (224x280 from 256x320 frames, trainer_end_to_end_video.py:61)
     "vits_224x280_t2": (dict(VITS, image_shape=(224, 280), lora_type="dvlora", disable_conv_head=True), (1, 2, 256, 320), "tissue", "strided"),
     "vits_224x280_conv_t2": (dict(VITS, image_shape=(224, 280), lora_type="dvlora"), (1, 2, 256, 320), "tissue", "strided"),
@@ -32,5 +39,6 @@ CASES = {
     "vits_518_t4": (dict(VITS, image_shape=(518, 518), lora_type="dvlora", disable_conv_head=True), (1, 4, 518, 518), "uniform", "strided"),
 }
 
+DASH_WARMUP_CALLS = 100  # mylora/layers.py:542 (self.warmup)
 # cases replayed by the (CPU) oracle test on every run; the 518 case takes ~5 s
 STAGE_KEYS = ("tokens", "block0", "tap0", "tap3", "mm0", "mm1", "path4", "path3", "path2", "path1")

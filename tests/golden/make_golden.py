@@ -158,6 +158,8 @@ def dump_state_keys(ref):
         "vits_dash_conv": dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384], lora_type="dash"),
         "vits_none_vda": dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384], lora_type="none", disable_conv_head=True),
         "vitl_dvlora_vda": dict(encoder="vitl", features=256, out_channels=[256, 512, 1024, 1024], lora_type="dvlora", disable_conv_head=True),
+        "vits_clstoken_resblocks": dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384], lora_type="dvlora", use_clstoken=True,
+                                        residual_block_indexes=[2, 5, 8, 11]),
     }
     out = {}
     for name, kw in combos.items():
@@ -191,14 +193,20 @@ def main(argv):
             model = ref.endodav(**kwargs, pretrained_path=None).eval()
         synth.fill_module_(model)
         x = torch.from_numpy(synth.synth_clip(B, T, H, W, seed=1, kind=kind))
+        dash_active = name.endswith("_dash_active")
         with torch.no_grad():
+            if dash_active:  # DashLinear switches its SVD term on at call 101 (mylora/layers.py:558-583)
+                from tests.golden.cases import DASH_WARMUP_CALLS
+                for _ in range(DASH_WARMUP_CALLS):
+                    model(x[:, :1])
             out_ref = model(x)
         sd = {k: v.detach() for k, v in model.state_dict().items()}
         cfg = orc.OracleConfig(
             encoder=kwargs["encoder"], image_shape=tuple(kwargs["image_shape"]), lora_type=kwargs.get("lora_type", "lora"),
             r=kwargs.get("r", 4), include_cls_token=kwargs.get("include_cls_token", True),
             disable_conv_head=kwargs.get("disable_conv_head", False), inv_sigmoid=kwargs.get("inv_sigmoid", False),
-            out_sigmoid=kwargs.get("out_sigmoid", False))
+            out_sigmoid=kwargs.get("out_sigmoid", False), use_clstoken=kwargs.get("use_clstoken", False),
+            residual_block_indexes=tuple(kwargs.get("residual_block_indexes", ())), dash_active=dash_active)
         stages = {}
         with torch.no_grad():
             out_orc = orc.forward(sd, x, cfg, stages)

@@ -14,8 +14,10 @@ from tests.golden.cases import CASES
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
-def oracle_config(kwargs) -> orc.OracleConfig:
+def oracle_config(kwargs, dash_active: bool = False) -> orc.OracleConfig:
     return orc.OracleConfig(
+        use_clstoken=kwargs.get("use_clstoken", False), residual_block_indexes=tuple(kwargs.get("residual_block_indexes", ())),
+        dash_active=dash_active,
         encoder=kwargs["encoder"], image_shape=tuple(kwargs["image_shape"]), lora_type=kwargs.get("lora_type", "lora"),
         r=kwargs.get("r", 4), include_cls_token=kwargs.get("include_cls_token", True),
         disable_conv_head=kwargs.get("disable_conv_head", False), inv_sigmoid=kwargs.get("inv_sigmoid", False),
@@ -29,6 +31,10 @@ def build_model(name: str):
     kwargs, shape, kind, store = CASES[name]
     model = endodav_amd.endodav(**kwargs, pretrained_path=None).eval()
     synth.fill_module_(model)
+    if name.endswith("_dash_active"):
+        from tests.golden.cases import DASH_WARMUP_CALLS
+
+        model._dash_calls = DASH_WARMUP_CALLS  # the next forward is call 101: SVD selection + active term
     return model, kwargs, shape, kind, store
 
 

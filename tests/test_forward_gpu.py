@@ -68,7 +68,7 @@ def test_micro_cases_match_reference_golden(cuda, name):
     check_against_golden(name, out, "full")
 
 
-@pytest.mark.parametrize("name", ["vits_224x280_t2", "vits_224x280_conv_t2", "vits_518_t4"])
+@pytest.mark.parametrize("name", ["vits_224x280_t2", "vits_224x280_conv_t2", "vits_518_t4", "resblock_224x280"])
 def test_full_size_cases_match_reference_golden(cuda, name):
     _, _, _, out = run_hip(name, cuda)
     check_against_golden(name, out, "strided", all_pixels=True)
@@ -160,3 +160,20 @@ def test_errors_are_loud(cuda):
         endodav_amd.endodav(encoder="vitx")
     with pytest.raises(NotImplementedError):  # grads enabled + trainable LoRA: backward is not built
         model(x)
+    # residual blocks away from the reference's hard-wired 16x20 grid: its reshape fails, so does ours
+    bad = endodav_amd.endodav(encoder="vits", features=32, out_channels=[32, 32, 64, 64], image_shape=(42, 56), residual_block_indexes=[2]).to(cuda)
+    with pytest.raises(RuntimeError, match="16, 20"):
+        with torch.no_grad():
+            bad(torch.rand(1, 1, 3, 42, 56, device=cuda))
+
+
+def test_dash_state_machine_matches_reference(cuda):
+    """Calls 1..100 are plain LoRA (golden micro_dash); call 101 selects the SVD directions and folds the extra term
+    (golden micro_dash_active, captured after 100 warm-up calls of the reference)."""
+    model, kwargs, x, out = run_hip("micro_dash", cuda)
+    assert model._dash_calls == 1 and model._config().dash_active == 0
+    check_against_golden("micro_dash", out, "full")
+    model2, _, x2, out2 = run_hip("micro_dash_active", cuda)
+    assert model2._dash_calls == 101 and model2._config().dash_active == 1
+    assert all(m.lora_index.requires_grad for m in model2._dash_layers())
+    check_against_golden("micro_dash_active", out2, "full")

@@ -18,10 +18,14 @@ FULL = [n for n in CASES if not n.startswith("micro_")]
 def _replay(name):
     model, kwargs, shape, kind, store = H.build_model(name)
     x = H.case_input(name)
+    dash_active = name.endswith("_dash_active")
+    if dash_active:  # host-side state machine of DashLinear: call 101 runs the SVD selection (pure torch, CPU here)
+        model._dash_step()
+        assert model._dash_calls == 101 and model._config().dash_active == 1
     sd = {k: v.detach() for k, v in model.state_dict().items()}
     stages = {}
     with torch.no_grad():
-        out = orc.forward(sd, x, H.oracle_config(kwargs), stages)
+        out = orc.forward(sd, x, H.oracle_config(kwargs, dash_active), stages)
     g = H.load_golden(name)
     assert float(g["oracle_vs_reference_maxrel"]) < 2e-5  # recorded when the fixture was made
     for s in range(4):

@@ -147,6 +147,57 @@ def make_video_golden(ref):
     print(f"video_stitch: {len(seen)} windows, out mean {out.mean():.4f}; wrote {os.path.getsize(path)} B")
 
 
+def metrics_inputs():
+    """Deterministic inputs of the metric known-answer test (regenerated identically by tests/test_evaluate_cpu.py)."""
+    from endodav_amd import synth
+
+    h, w = 40, 56
+    gt = synth.uniform("kat:gt", (3, h, w), 5.0, 120.0).astype(np.float32)
+    gt[0, :4] = 0.0          # invalid rows (below MIN_DEPTH)
+    gt[1, -3:] = 200.0       # above MAX_DEPTH
+    pred = (gt * synth.uniform("kat:noise", (3, h, w), 0.8, 1.3) + 1.0).astype(np.float32)
+    disp = synth.uniform("kat:disp", (3, h, w), 0.0, 1.0).astype(np.float32)
+    K = np.eye(4)
+    K[0, 0] = K[1, 1] = 50.0
+    K[0, 2], K[1, 2] = w / 2.0, h / 2.0
+    pose_a, pose_b = np.eye(4), np.eye(4)
+    pose_b[0, 3], pose_b[2, 3] = 0.8, -0.5
+    smooth = (30.0 + 10.0 * np.sin(np.arange(w)[None, :] / 9.0) + 5.0 * np.cos(np.arange(h)[:, None] / 7.0)).astype(np.float32)
+    return dict(gt=gt, pred=pred, disp=disp, K=K, pose_a=pose_a, pose_b=pose_b, depth_a=smooth, depth_b=(smooth * 1.03 + 0.4).astype(np.float32))
+
+
+def make_metrics_kat():
+    """Known answers of the reference's metric helpers (utils/utils.py:112-133, utils/layers.py:11-20,
+    utils/eval_utils.py:63-143,265-282) on the deterministic inputs above."""
+    im = types.ModuleType("imageio")
+    imv2 = types.ModuleType("imageio.v2")
+    im.v2 = imv2
+    sys.modules.setdefault("imageio", im)
+    sys.modules.setdefault("imageio.v2", imv2)  # import-time only (video writers), never called here
+    from utils.utils import compute_errors
+    from utils.layers import disp_to_depth
+    from utils import eval_utils as eu
+
+    x = metrics_inputs()
+    out = {}
+    valid = np.logical_and(x["gt"] > 1e-3, x["gt"] < 150)
+    out["compute_errors"] = np.array(compute_errors(x["gt"], x["pred"], valid), dtype=np.float64)
+    sd, d = disp_to_depth(x["disp"], 0.1, 150.0)
+    out["scaled_disp"], out["depth"] = sd, d
+    ms, ratio = eu.median_scaling(x["gt"].copy(), x["pred"].copy())
+    out["median_scaled"], out["median_ratio"] = ms, np.float64(ratio)
+    al, t_gt, s_gt, t_pred, s_pred = eu.align_shift_and_scale(x["gt"].copy(), x["pred"].copy())
+    out["aligned"], out["align_params"] = al, np.array([t_gt, s_gt, t_pred, s_pred], dtype=np.float64)
+    mask = np.ones_like(x["depth_a"], dtype=bool)
+    mask[:3] = False
+    i2w_a, i2w_b = np.linalg.inv(x["K"] @ x["pose_a"]), np.linalg.inv(x["K"] @ x["pose_b"])
+    out["tae"] = np.float64(eu.tae(x["depth_a"], mask, i2w_a, x["depth_b"], mask, i2w_b))
+    out["tas"] = np.float64(eu.tas(x["depth_a"], mask, i2w_a, x["depth_b"], mask, i2w_b))
+    path = os.path.join(HERE, "metrics_kat.npz")
+    np.savez_compressed(path, **out)
+    print(f"metrics_kat: errors {out['compute_errors'][:3]}, tae {out['tae']:.5f}, tas {out['tas']:.4f}; wrote {os.path.getsize(path)} B")
+
+
 def dump_state_keys(ref):
     """state_dict key -> shape listings of the reference for the drop-in check."""
     import json
@@ -184,7 +235,9 @@ def main(argv):
         make_video_golden(ref)
     if not argv or "keys" in argv:
         dump_state_keys(ref)
-    names = [a for a in argv if a not in ("video", "keys")] if argv else list(CASES)
+    if not argv or "metrics" in argv:
+        make_metrics_kat()
+    names = [a for a in argv if a not in ("video", "keys", "metrics")] if argv else list(CASES)
     torch.set_num_threads(8)
     for name in names:
         kwargs, (B, T, H, W), kind, store = CASES[name]

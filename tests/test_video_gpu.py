@@ -48,3 +48,16 @@ def test_real_video_run_with_native_resolution_resize(cuda):
     # a one-window video needs no stitching: frame i must equal the direct forward on the resized clip
     out2 = model.infer_video_depth(frames, device="cuda:0")
     assert np.array_equal(out, out2)
+
+
+def test_evaluate_video_end_to_end(cuda):
+    """evaluate_depth_video.py's loop on synthetic clips through the real HIP model: plumbing + report format."""
+    from endodav_amd import evaluate as ev
+
+    model = _model(42, 56, cuda)
+    ds = ev.SyntheticVideos(n_clips=2, n_frames=5, height=42, width=56)
+    res = ev.evaluate_video(model, ds, depth_align="scale_shift", device="cuda:0")
+    assert res["errors"].shape == (10, 7) and res["temporal"].shape == (8, 2) and np.isfinite(res["errors"]).all()
+    assert len(res["inference_times"]) == 2 and res["aligns"].shape == (2, 4)
+    txt = ev.format_results(res)
+    assert txt.startswith("    abs_rel") and "average inference time" in txt

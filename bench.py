@@ -43,13 +43,14 @@ def parse():
     ap.add_argument("--T", type=int, default=8, help="frames per clip (BASELINE headline: 8)")
     ap.add_argument("--encoder", default="vits", choices=sorted(MODELS))
     ap.add_argument("--image", type=int, default=518)
+    ap.add_argument("--clips", type=int, default=1, help="clips per GPU per step (a batch [B,T,...] through one forward)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with HIP events")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(16, cores): the box's CPU share)")
     return ap.parse_args()
 
 
-def measured_traffic(encoder, T, image):
+def measured_traffic(encoder, T, image, clips=1):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (collected in
     their own runs, FETCH_SIZE doubled as the gfx950 guide prescribes); None when no pass matches this workload."""
     path = os.path.join(ROOT, "profiles", "r01_attn_traffic.json")
@@ -58,7 +59,7 @@ def measured_traffic(encoder, T, image):
             rec = json.load(f)
     except OSError:
         return None
-    if rec.get("config") == {"encoder": encoder, "T": T, "image": image}:
+    if rec.get("config") == {"encoder": encoder, "T": T, "image": image} and clips == 1:
         return rec["traffic_bytes_per_launch"]
     return None
 
@@ -114,7 +115,8 @@ def main():
     model = endodav_amd.endodav(**kwargs, image_shape=(S, S), lora_type="dvlora", disable_conv_head=True).eval()
     synth.fill_module_(model)
     model = model.to(dev)
-    x = torch.from_numpy(synth.synth_clip(1, T, S, S, seed=rank)).to(dev)  # resident in HBM before timing
+    Bc = args.clips
+    x = torch.from_numpy(synth.synth_clip(Bc, T, S, S, seed=rank)).to(dev)  # resident in HBM before timing
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -140,13 +142,13 @@ def main():
         n, ms = model.profile_read("attn_spatial")
         D, depth, heads = DIMS[args.encoder]
         ntok = (S // 14) ** 2 + 1
-        flops = 4.0 * ntok * ntok * 64 * heads * T  # QK^T + PV, 2 FLOP per MAC, per launch (one encoder block, T frames)
+        flops = 4.0 * ntok * ntok * 64 * heads * T * Bc  # QK^T + PV, 2 FLOP per MAC, per launch (one encoder block, all frames)
         if n > 0 and ms > 0:
             achieved = flops / (ms / n * 1e-3) / 1e12
             roofline = {"kernel": "attn_spatial_kernel", "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(args.encoder, T, S),
+                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(args.encoder, T, S, Bc),
                         "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_attn_traffic.json)",
-                        "algorithmic_bytes_per_launch": 4.0 * ntok * T * heads * 64 * 4,
+                        "algorithmic_bytes_per_launch": 4.0 * ntok * T * Bc * heads * 64 * 4,
                         "launches": n, "avg_launch_ms": round(ms / n, 4), "flop_per_launch": flops,
                         "peak_dtype": "f32 MFMA (v_mfma_f32_32x32x2_f32), dense"}
     # PCIe-inclusive variant (never `value`): pinned host clip -> HBM, forward, the four maps -> pinned host
@@ -165,10 +167,10 @@ def main():
                 for h, v in zip(oh, o.values()):
                     h.copy_(v, non_blocking=True)
             torch.cuda.synchronize(dev)
-            pcie_value = T * n_p / (time.perf_counter() - t1)
+            pcie_value = Bc * T * n_p / (time.perf_counter() - t1)
     finite = bool(torch.isfinite(out[("disp", 0)]).all().item())
     if rank == 0:
-        frames = world * T * args.steps
+        frames = world * Bc * T * args.steps
         value = frames / dt
         line = {
             "metric": "depth frames/sec (518x518, T=8 clip)" if (S, T) == (518, 8) else f"depth frames/sec ({S}x{S}, T={T} clip)",
@@ -176,8 +178,8 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"ViT-{args.encoder[-1].upper()} endodav (features {kwargs['features']}, out_channels {kwargs['out_channels']}, "
-                                   f"dvlora r=4, VDA head), one synthetic {S}x{S} T={T} clip per GPU per step (BASELINE.json configs[1] shape), "
-                                   "hash-initialised weights", "encoder": args.encoder, "T": T, "image": [S, S], "clips_per_gpu_per_step": 1,
+                                   f"dvlora r=4, VDA head), {Bc} synthetic {S}x{S} T={T} clip(s) per GPU per step (BASELINE.json configs[1] shape), "
+                                   "hash-initialised weights", "encoder": args.encoder, "T": T, "image": [S, S], "clips_per_gpu_per_step": Bc,
                        "parallelism": f"clip-sharded x{world}, no data-path collective"},
             "model_tflop_per_clip": round(GFLOP_PER_FRAME[args.encoder] * T / 1e3 * (S / 518.0) ** 2, 4),
             "model_tflops": round(GFLOP_PER_FRAME[args.encoder] * (S / 518.0) ** 2 * value / 1e3, 2),

@@ -10,7 +10,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libendodav_hip.so")
+LIB_PATH = os.environ.get("EDV_LIB_PATH") or os.path.join(_HERE, "lib", "libendodav_hip.so")  # override: experiments only
 ABI_VERSION = 2
 
 LORA_TYPES = {"none": 0, "lora": 1, "dvlora": 2, "ssb": 3, "dash": 4}
@@ -66,6 +66,8 @@ SIGNATURES = {
     "edv_last_launch_count": (C.c_int, [C.c_void_p]),
     "edv_layernorm": (C.c_int, [_fp, _fp, _fp, _fp, _i64, _i32, _f32, _fp, _i32, _i32, C.c_void_p]),
     "edv_gemm": (C.c_int, [_fp, _fp, _fp, _i64, _i32, _i32, _fp, _i32, _fp, _fp, C.c_void_p]),
+    "edv_gemm_sb": (C.c_int, [_fp, _fp, _fp, _fp, _i64, _i32, _i32, _fp, _i32, _fp, _fp, C.c_void_p]),
+    "edv_conv3x3_sb": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _fp, _fp, C.c_void_p]),
     "edv_conv3x3": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _fp, _fp, C.c_void_p]),
     "edv_pack_conv3x3": (C.c_int, [_fp, _fp, _i32, _i32, C.c_void_p]),
     "edv_conv_transpose": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),

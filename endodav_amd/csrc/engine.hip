@@ -11,6 +11,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <unordered_map>
@@ -52,6 +53,9 @@ struct edv_ctx {
     edv_config cfg{};
     unsigned prof_mask = 0;
     EvPool prof[KC_COUNT];
+    int enc_streams = 1;                      // 2: run the two halves of the frame batch through the encoder concurrently
+    hipStream_t sub[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     std::unordered_map<std::string, Param> params;
     std::unordered_map<std::string, Buf> packed;  // derived weights, owned
     std::unordered_map<std::string, Buf> ws;      // activations, owned
@@ -114,6 +118,7 @@ struct Run {
     const edv_config &cfg;
     int D, depth, heads, Fe;
     int F = 0, B = 0, T = 0, ph = 0, pw = 0, P0 = 0, ntok = 0, c0 = 0;
+    std::string rb_suffix;
 
     Run(edv_ctx *ctx, hipStream_t s) : c(ctx), st(s), cfg(ctx->cfg) {
         D = cfg.embed_dim;
@@ -430,9 +435,9 @@ struct Run {
         const int Cb = D / 8;
         const long long MP = (long long)F * P0;
         float *t1, *t2, *t3;
-        EDV_TRY(wsbuf("rb.t1", (size_t)MP * Cb, &t1));
-        EDV_TRY(wsbuf("rb.t2", (size_t)MP * Cb, &t2));
-        EDV_TRY(wsbuf("rb.t3", (size_t)MP * D, &t3));
+        EDV_TRY(wsbuf("rb.t1" + rb_suffix, (size_t)MP * Cb, &t1));
+        EDV_TRY(wsbuf("rb.t2" + rb_suffix, (size_t)MP * Cb, &t2));
+        EDV_TRY(wsbuf("rb.t3" + rb_suffix, (size_t)MP * D, &t3));
         const float *w, *nw, *nb;
         EDV_TRY(param(p + ".conv1.weight", &w, 4));
         {
@@ -459,33 +464,35 @@ struct Run {
         return 0;
     }
 
-    int forward(const float *x, int B_, int T_, int H, int W, float *const disp[4]) {
-        B = B_; T = T_; F = B * T;
-        ph = cfg.image_h / 14; pw = cfg.image_w / 14; P0 = ph * pw;
-        c0 = cfg.include_cls_token ? 1 : 0;
-        ntok = P0 + c0;
-        c->launches = 0;
-        c->stages.clear();
-        c->F = F; c->T = T; c->ph = ph; c->pw = pw; c->ntok = ntok;
-        const long long MT = (long long)F * ntok;
-        const int *oc = cfg.out_channels;
-
-        // ---------------- encoder ----------------
+    struct EncBufs {
         float *cols, *xt, *xn, *qkv, *att, *hid;
-        EDV_TRY(wsbuf("cols", (size_t)F * P0 * 588, &cols));
-        EDV_TRY(wsbuf("xt", (size_t)MT * D, &xt));
-        EDV_TRY(wsbuf("xn", (size_t)MT * D, &xn));
-        EDV_TRY(wsbuf("qkv", (size_t)MT * 3 * D, &qkv));
-        EDV_TRY(wsbuf("att", (size_t)MT * D, &att));
-        EDV_TRY(wsbuf("hid", (size_t)MT * 4 * D, &hid));
-        float *tap[4], *tapcls[4] = {nullptr, nullptr, nullptr, nullptr};
-        for (int j = 0; j < 4; ++j) EDV_TRY(wsbuf("tap" + std::to_string(j), (size_t)F * P0 * D, &tap[j]));
-        if (cfg.use_clstoken)
-            for (int j = 0; j < 4; ++j) EDV_TRY(wsbuf("tapcls" + std::to_string(j), (size_t)F * D, &tapcls[j]));
-
+        float *tap[4], *tapcls[4];
         const float *pos;
-        EDV_TRY(pos_table(&pos));
-        EDV_TRY(patchify(x, cols, F, H, W, cfg.image_h, cfg.image_w, st));
+    };
+    int ensure_streams() {
+        if (c->sub[0]) return 0;
+        for (int h = 0; h < 2; ++h) {
+            EDV_HIP(hipStreamCreateWithFlags(&c->sub[h], hipStreamNonBlocking));
+            EDV_HIP(hipEventCreateWithFlags(&c->ev_join[h], hipEventDisableTiming));
+        }
+        EDV_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        return 0;
+    }
+    // encoder on frames [f0, f0 + nf) enqueued on stream s (vision_transformer.py:279-289 + :317-321)
+    int encoder_range(const EncBufs &eb, const float *x, int f0, int nf, int H, int W, hipStream_t s) {
+        st = s;
+        F = nf;
+        const long long MT = (long long)nf * ntok;
+        float *cols = eb.cols + (size_t)f0 * P0 * 588, *xt = eb.xt + (size_t)f0 * ntok * D, *xn = eb.xn + (size_t)f0 * ntok * D;
+        float *qkv = eb.qkv + (size_t)f0 * ntok * 3 * D, *att = eb.att + (size_t)f0 * ntok * D, *hid = eb.hid + (size_t)f0 * ntok * 4 * D;
+        float *tap[4], *tapcls[4];
+        for (int j = 0; j < 4; ++j) {
+            tap[j] = eb.tap[j] + (size_t)f0 * P0 * D;
+            tapcls[j] = eb.tapcls[j] ? eb.tapcls[j] + (size_t)f0 * D : nullptr;
+        }
+        const float *pos = eb.pos;
+        rb_suffix = f0 == 0 ? "" : ".b";
+        EDV_TRY(patchify(x + (size_t)f0 * 3 * H * W, cols, F, H, W, cfg.image_h, cfg.image_w, st));
         c->launches++;
         {
             const float *w, *b;
@@ -537,14 +544,64 @@ struct Run {
             if (tapj < 4 && i == cfg.taps[tapj]) {
                 // final norm on the tap, cls row dropped (vision_transformer.py:317-321)
                 EDV_TRY(ln(xt, RowMap{P0, ntok, c0}, "pretrained.norm", tap[tapj], (long long)F * P0, D, 1e-6f));
-                c->stages["tap" + std::to_string(tapj)] = {tap[tapj], (size_t)F * P0 * D};
-                // token 0 of every frame, normed: the cls token, or with include_cls_token=False the first patch
+                                // token 0 of every frame, normed: the cls token, or with include_cls_token=False the first patch
                 // ("not real cls tokens", vision_transformer.py:322-324)
                 if (cfg.use_clstoken) EDV_TRY(ln(xt, RowMap{1, ntok, 0}, "pretrained.norm", tapcls[tapj], F, D, 1e-6f));
                 ++tapj;
             }
         }
         EDV_CHECK(tapj == 4, "taps must be increasing block indices < depth");
+        return 0;
+    }
+
+    int forward(const float *x, int B_, int T_, int H, int W, float *const disp[4]) {
+        B = B_; T = T_; F = B * T;
+        ph = cfg.image_h / 14; pw = cfg.image_w / 14; P0 = ph * pw;
+        c0 = cfg.include_cls_token ? 1 : 0;
+        ntok = P0 + c0;
+        c->launches = 0;
+        c->stages.clear();
+        c->F = F; c->T = T; c->ph = ph; c->pw = pw; c->ntok = ntok;
+        const long long MT = (long long)F * ntok;
+        const int *oc = cfg.out_channels;
+
+        // ---------------- encoder ----------------
+        float *cols, *xt, *xn, *qkv, *att, *hid;
+        EDV_TRY(wsbuf("cols", (size_t)F * P0 * 588, &cols));
+        EDV_TRY(wsbuf("xt", (size_t)MT * D, &xt));
+        EDV_TRY(wsbuf("xn", (size_t)MT * D, &xn));
+        EDV_TRY(wsbuf("qkv", (size_t)MT * 3 * D, &qkv));
+        EDV_TRY(wsbuf("att", (size_t)MT * D, &att));
+        EDV_TRY(wsbuf("hid", (size_t)MT * 4 * D, &hid));
+        float *tap[4], *tapcls[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int j = 0; j < 4; ++j) EDV_TRY(wsbuf("tap" + std::to_string(j), (size_t)F * P0 * D, &tap[j]));
+        if (cfg.use_clstoken)
+            for (int j = 0; j < 4; ++j) EDV_TRY(wsbuf("tapcls" + std::to_string(j), (size_t)F * D, &tapcls[j]));
+
+        const float *pos;
+        EDV_TRY(pos_table(&pos));
+        EncBufs eb{cols, xt, xn, qkv, att, hid, {tap[0], tap[1], tap[2], tap[3]}, {tapcls[0], tapcls[1], tapcls[2], tapcls[3]}, pos};
+        // Frames are independent in the encoder: with two internal streams the two halves of the batch run as
+        // concurrent kernels, so workgroups of different kernels (one half's attention, the other's GEMM) co-reside
+        // on the CUs and fill each other's stalls and grid tails.  The head needs all T frames again (temporal attention).
+        const int nstreams = (c->enc_streams > 1 && F >= 2 && !c->capture) ? 2 : 1;
+        if (nstreams == 1) {
+            EDV_TRY(encoder_range(eb, x, 0, F, H, W, st));
+        } else {
+            EDV_TRY(ensure_streams());
+            const int Fa = (F + 1) / 2, Fall = F;
+            hipStream_t user = st;
+            EDV_HIP(hipEventRecord(c->ev_fork, user));
+            for (int h = 0; h < 2; ++h) {
+                EDV_HIP(hipStreamWaitEvent(c->sub[h], c->ev_fork, 0));
+                const int rc = encoder_range(eb, x, h == 0 ? 0 : Fa, h == 0 ? Fa : Fall - Fa, H, W, c->sub[h]);
+                st = user; F = Fall;
+                if (rc) return rc;
+                EDV_HIP(hipEventRecord(c->ev_join[h], c->sub[h]));
+                EDV_HIP(hipStreamWaitEvent(user, c->ev_join[h], 0));
+            }
+        }
+        for (int j = 0; j < 4; ++j) c->stages["tap" + std::to_string(j)] = {tap[j], (size_t)F * P0 * D};
 
         // ---------------- DPT head: reassemble ----------------
         const long long MP = (long long)F * P0;
@@ -737,6 +794,7 @@ int edv_create(const edv_config *cfg, edv_ctx **out) {
     for (int j = 0; j < 4; ++j) EDV_CHECK(cfg->taps[j] >= 0 && cfg->taps[j] < cfg->depth && (j == 0 || cfg->taps[j] > cfg->taps[j - 1]), "taps");
     *out = new edv_ctx();
     (*out)->cfg = *cfg;
+    if (const char *e = getenv("EDV_ENC_STREAMS")) (*out)->enc_streams = atoi(e);
     return 0;
 }
 
@@ -747,6 +805,11 @@ int edv_destroy(edv_ctx *ctx) {
         if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto &kv : ctx->ws)
         if (kv.second.p) (void)hipFree(kv.second.p);
+    for (int h = 0; h < 2; ++h) {
+        if (ctx->sub[h]) (void)hipStreamDestroy(ctx->sub[h]);
+        if (ctx->ev_join[h]) (void)hipEventDestroy(ctx->ev_join[h]);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     for (auto &p : ctx->prof)
         for (auto &e : p.ev) {
             (void)hipEventDestroy(e.first);

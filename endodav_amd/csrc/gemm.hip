@@ -17,23 +17,14 @@
 // permutation of k, so the sum over k is unchanged, and LDS traffic drops to one b128 per 4 MFMAs.
 #include <cstdlib>
 
-#include "ops.hpp"
+#include "gemm_common.hpp"
 
 namespace edv {
-
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 namespace {
 
 constexpr int BK = 32;
 constexpr int LS = BK + 4;  // padded LDS row stride (floats)
-
-__device__ __forceinline__ float apply_act(float v, int act) {
-    if (act == ACT_GELU) return gelu_erf(v);
-    if (act == ACT_RELU) return fmaxf(v, 0.0f);
-    return v;
-}
 
 template <int BM, int BN, int WGM, int WGN, int LOADER, int STORE>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc g) {
@@ -54,11 +45,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc g) {
     // XCD-aware, bijective block remap: blocks b and b+8 share an XCD (and its L2); give each XCD a
     // contiguous run of tiles, n fastest, so the column tiles of one A row-panel hit the same L2.
     const int tiles_n = (g.N + BN - 1) / BN;
-    int bid = blockIdx.x;
-    {
-        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, x = bid & 7, loc = bid >> 3;
-        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
-    }
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
     const long long m0 = (long long)tm * BM;
     const int n0 = tn * BN;
@@ -192,45 +179,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc g) {
         __syncthreads();
     }
 
-    // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-        const int n = n0 + wn * WTN + j * 32 + l31;
-        if (n >= g.N) continue;
-        const float bias = g.bias ? g.bias[n] : 0.f;
-        const float gam = g.gamma ? g.gamma[n] : 1.f;
-        int ps_sub = 0, ps_co = 0, ps_dy = 0, ps_dx = 0;
-        if (STORE == STORE_SHUFFLE) {
-            ps_sub = n / g.ps_C;
-            ps_co = n - ps_sub * g.ps_C;
-            ps_dy = ps_sub / g.ps_s;
-            ps_dx = ps_sub - ps_dy * g.ps_s;
-        }
-#pragma unroll
-        for (int i = 0; i < FM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const long long m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m >= g.M) continue;
-                float pre = acc[i][j][r] + bias;
-                if (g.P1) pre += g.P1[g.p1_map(m) * g.ldp1 + n];
-                float v = apply_act(pre, g.act) * gam;
-                if (STORE == STORE_ROWS) {
-                    const long long crow = g.c_map(m);
-                    if (g.R1) v += g.R1[g.r1_map(m) * g.ldr1 + n];
-                    if (g.R2) v += g.R2[crow * g.ldr2 + n];
-                    g.C[crow * g.ldc + n] = v;
-                } else {
-                    const int gp = g.ps_h * g.ps_w;
-                    const long long f = m / gp;
-                    const int p = (int)(m - f * gp);
-                    const int y = p / g.ps_w, x = p - y * g.ps_w;
-                    const long long orow = (f * g.ps_h * g.ps_s + (long long)y * g.ps_s + ps_dy) * (g.ps_w * g.ps_s) + x * g.ps_s + ps_dx;
-                    g.C[orow * g.ps_C + ps_co] = v;
-                }
-            }
-        }
-    }
+    gemm_epilogue<FM, FN, STORE>(g, acc, m0, n0, wm * WTM, wn * WTN, l31, lh);
 }
 
 template <int BM, int BN, int WGM, int WGN>

@@ -35,6 +35,17 @@ def gemm(M, N, K, act=0, res=False, label=""):
     print(f"gemm {label:10s} M={M:6d} N={N:5d} K={K:5d} act={act} res={int(res)}: {t*1e6:8.1f} us  {2*M*N*K/t/1e12:6.1f} TF", flush=True)
 
 
+def gemm_sb(M, N, K, act=0, res=False, label=""):
+    A = torch.randn(M, K, device=dev)
+    W = torch.randn(N, K, device=dev) * 0.05
+    planes = torch.empty(3 * N * K, dtype=torch.bfloat16, device=dev)
+    Cm = torch.empty(M, N, device=dev)
+    b = torch.randn(N, device=dev)
+    R = torch.randn(M, N, device=dev) if res else None
+    t = timeit(lambda: _lib.check(lib.edv_gemm_sb(A.data_ptr(), W.data_ptr(), planes.data_ptr(), Cm.data_ptr(), M, N, K, b.data_ptr(), act, None, _lib.ptr(R), st())))
+    print(f"gemm_sb {label:10s} M={M:6d} N={N:5d} K={K:5d} act={act} res={int(res)}: {t*1e6:8.1f} us  {2*M*N*K/t/1e12:6.1f} TF-eq (incl. W split)", flush=True)
+
+
 def attn(F, N, heads):
     qkv = torch.randn(F * N, 3 * heads * 64, device=dev)
     o = torch.empty(F * N, heads * 64, device=dev)
@@ -42,7 +53,18 @@ def attn(F, N, heads):
     print(f"attn F={F} N={N} heads={heads}: {t*1e6:8.1f} us  {4*N*N*64*heads*F/t/1e12:6.1f} TF", flush=True)
 
 
-if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "sweep":
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "sb":
+    import os
+    print("EDV_SB_TILE", os.environ.get("EDV_SB_TILE"))
+    for T in (8, 32):
+        M = T * 1370
+        gemm_sb(M, 1152, 384, label=f"qkv T{T}")
+        gemm_sb(M, 1536, 384, act=1, label=f"fc1 T{T}")
+        gemm_sb(M, 384, 384, res=True, label=f"proj T{T}")
+        gemm_sb(M, 384, 1536, res=True, label=f"fc2 T{T}")
+    gemm_sb(8192, 8192, 1024, label="8k8k1k")
+    gemm_sb(4096, 4096, 4096, label="4096^3")
+elif __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "sweep":
     import os
     print("EDV_GEMM_TILE", os.environ.get("EDV_GEMM_TILE"), "EDV_ATTN_WAVES", os.environ.get("EDV_ATTN_WAVES"))
     for T in (8, 4):

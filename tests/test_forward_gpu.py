@@ -134,6 +134,45 @@ def test_baseline_config_vits_518_t8_against_oracle(cuda):
         assert e <= DISP_RTOL and de <= DEPTH_RTOL and ar <= ABS_REL_MAX
 
 
+@pytest.mark.parametrize("encoder,features,out_channels,T", [("vitb", 128, [96, 192, 384, 768], 2), ("vitl", 256, [256, 512, 1024, 1024], 1)])
+def test_larger_encoders_full_size_against_oracle(cuda, encoder, features, out_channels, T):
+    """BASELINE configs 3 and 5 use ViT-B / ViT-L at 518x518: full-size parity against the CPU oracle.  (ViT-L goes
+    through the bicubic position-table resample: its stored pos_embed has 257 rows)"""
+    import endodav_amd
+    from endodav_amd import synth
+
+    kwargs = dict(encoder=encoder, features=features, out_channels=out_channels, image_shape=(518, 518), lora_type="dvlora", disable_conv_head=True)
+    model = endodav_amd.endodav(**kwargs).eval()
+    synth.fill_module_(model)
+    x = torch.from_numpy(synth.synth_clip(1, T, 518, 518, seed=5, kind="tissue"))
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        ref = orc.forward(sd, x, H.oracle_config(kwargs))
+    model = model.to(cuda)
+    with torch.no_grad():
+        out = model(x.to(cuda))
+    for s in range(4):
+        a, b = out[("disp", s)].cpu().numpy(), ref[("disp", s)].numpy()
+        e, ar = H.rel_err(a, b), H.abs_rel(a, b)
+        de, excl = H.depth_gate(a, b)
+        print(f"\n[{encoder} 518 T={T}] disp{s}: scale-rel {e:.2e}, abs_rel {ar:.2e}, max depth rel {de:.2e} ({excl:.2%} under the floor)")
+        assert e <= DISP_RTOL and de <= DEPTH_RTOL and ar <= ABS_REL_MAX
+
+
+def test_dual_stream_encoder_is_bit_identical(cuda):
+    """EDV_ENC_STREAMS=2 only changes which stream each half of the frame batch is enqueued on."""
+    import os
+
+    model, kwargs, x, out1 = run_hip("micro_t32", cuda)
+    os.environ["EDV_ENC_STREAMS"] = "2"
+    try:
+        model2, _, _, out2 = run_hip("micro_t32", cuda)
+    finally:
+        del os.environ["EDV_ENC_STREAMS"]
+    for s in range(4):
+        assert torch.equal(out1[("disp", s)], out2[("disp", s)])
+
+
 def test_weights_update_is_seen(cuda):
     """An optimizer-style in-place update of a bound tensor must re-fold the LoRA weights."""
     model, kwargs, x, out0 = run_hip("micro_vda_dvlora", cuda)

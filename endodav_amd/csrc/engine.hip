@@ -54,8 +54,8 @@ struct edv_ctx {
     unsigned prof_mask = 0;
     EvPool prof[KC_COUNT];
     int enc_streams = 1;                      // 2: run the two halves of the frame batch through the encoder concurrently
-    hipStream_t sub[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    hipStream_t sub[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     std::unordered_map<std::string, Param> params;
     std::unordered_map<std::string, Buf> packed;  // derived weights, owned
     std::unordered_map<std::string, Buf> ws;      // activations, owned
@@ -471,7 +471,7 @@ struct Run {
     };
     int ensure_streams() {
         if (c->sub[0]) return 0;
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < 4; ++h) {
             EDV_HIP(hipStreamCreateWithFlags(&c->sub[h], hipStreamNonBlocking));
             EDV_HIP(hipEventCreateWithFlags(&c->ev_join[h], hipEventDisableTiming));
         }
@@ -491,7 +491,7 @@ struct Run {
             tapcls[j] = eb.tapcls[j] ? eb.tapcls[j] + (size_t)f0 * D : nullptr;
         }
         const float *pos = eb.pos;
-        rb_suffix = f0 == 0 ? "" : ".b";
+        rb_suffix = "." + std::to_string(f0);
         EDV_TRY(patchify(x + (size_t)f0 * 3 * H * W, cols, F, H, W, cfg.image_h, cfg.image_w, st));
         c->launches++;
         {
@@ -584,21 +584,25 @@ struct Run {
         // Frames are independent in the encoder: with two internal streams the two halves of the batch run as
         // concurrent kernels, so workgroups of different kernels (one half's attention, the other's GEMM) co-reside
         // on the CUs and fill each other's stalls and grid tails.  The head needs all T frames again (temporal attention).
-        const int nstreams = (c->enc_streams > 1 && F >= 2 && !c->capture) ? 2 : 1;
+        int nstreams = (c->enc_streams > 1 && !c->capture) ? (c->enc_streams > 4 ? 4 : c->enc_streams) : 1;
+        if (nstreams > F) nstreams = F;
         if (nstreams == 1) {
             EDV_TRY(encoder_range(eb, x, 0, F, H, W, st));
         } else {
             EDV_TRY(ensure_streams());
-            const int Fa = (F + 1) / 2, Fall = F;
+            const int Fall = F;
             hipStream_t user = st;
             EDV_HIP(hipEventRecord(c->ev_fork, user));
-            for (int h = 0; h < 2; ++h) {
+            int f0 = 0;
+            for (int h = 0; h < nstreams; ++h) {
+                const int nf = (Fall - f0) / (nstreams - h);  // even split of the remaining frames
                 EDV_HIP(hipStreamWaitEvent(c->sub[h], c->ev_fork, 0));
-                const int rc = encoder_range(eb, x, h == 0 ? 0 : Fa, h == 0 ? Fa : Fall - Fa, H, W, c->sub[h]);
+                const int rc = encoder_range(eb, x, f0, nf, H, W, c->sub[h]);
                 st = user; F = Fall;
                 if (rc) return rc;
                 EDV_HIP(hipEventRecord(c->ev_join[h], c->sub[h]));
                 EDV_HIP(hipStreamWaitEvent(user, c->ev_join[h], 0));
+                f0 += nf;
             }
         }
         for (int j = 0; j < 4; ++j) c->stages["tap" + std::to_string(j)] = {tap[j], (size_t)F * P0 * D};
@@ -805,7 +809,7 @@ int edv_destroy(edv_ctx *ctx) {
         if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto &kv : ctx->ws)
         if (kv.second.p) (void)hipFree(kv.second.p);
-    for (int h = 0; h < 2; ++h) {
+    for (int h = 0; h < 4; ++h) {
         if (ctx->sub[h]) (void)hipStreamDestroy(ctx->sub[h]);
         if (ctx->ev_join[h]) (void)hipEventDestroy(ctx->ev_join[h]);
     }

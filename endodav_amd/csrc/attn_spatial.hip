@@ -27,11 +27,12 @@ using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int HD = 64;       // head dim
-constexpr int KT = 64;       // keys per LDS tile
 constexpr int KS = HD + 4;   // padded K row stride: 68r mod 64 = 4r -> conflict-free b128
 // NW waves per workgroup (NW*32 queries share the staged K/V tiles).  Fewer waves per workgroup means more,
 // smaller workgroups: better balance over the 256 CUs when frames*heads*ceil(N/128) is only ~2 per CU.
-template <int NW>
+// KT keys per LDS tile (32 or 64).  32-key tiles halve the prefetch and score registers (159 instead of 198 per lane:
+// 3 instead of 2 waves per SIMD) but measured no faster, so 64 stays the default; EDV_ATTN_KT=32 selects the other.
+template <int NW, int KT>
 __global__ __launch_bounds__(NW * 64) void attn_spatial_kernel(const float *__restrict__ qkv, float *__restrict__ out, int N, int heads) {
     constexpr int QB = NW * 32;
     constexpr int NT = NW * 64;
@@ -100,44 +101,49 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_kernel(const float *__re
         __syncthreads();
         if (t + 1 < ntiles) load_tile(k0 + KT);
 
-        // ---- Sᵀ = K Qᵀ : two 32-key sub-tiles
-        f32x16 s0, s1;
+        // ---- Sᵀ = K Qᵀ : KT/32 sub-tiles of 32 keys
+        constexpr int NS = KT / 32;
+        f32x16 sc[NS];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s0[r] = s1[r] = 0.f;
+        for (int u = 0; u < NS; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sc[u][r] = 0.f;
 #pragma unroll
         for (int qq = 0; qq < 8; ++qq) {
-            const f32x4 ka = *reinterpret_cast<const f32x4 *>(&sK[l31 * KS + 8 * qq + 4 * lh]);
-            const f32x4 kb = *reinterpret_cast<const f32x4 *>(&sK[(32 + l31) * KS + 8 * qq + 4 * lh]);
+            f32x4 kf[NS];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[e], qf[qq][e], s0, 0, 0, 0);
-                s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[e], qf[qq][e], s1, 0, 0, 0);
-            }
+            for (int u = 0; u < NS; ++u) kf[u] = *reinterpret_cast<const f32x4 *>(&sK[(32 * u + l31) * KS + 8 * qq + 4 * lh]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int u = 0; u < NS; ++u) sc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[u][e], qf[qq][e], sc[u], 0, 0, 0);
         }
         if (k0 + KT > N) {  // last tile: keys past the sequence end
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = k0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (key >= N) s0[r] = -INFINITY;
-                if (key + 32 >= N) s1[r] = -INFINITY;
-            }
+            for (int u = 0; u < NS; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (k0 + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * lh >= N) sc[u][r] = -INFINITY;
         }
 
-        // ---- online softmax in base 2; this lane holds 32 of its query's 64 scores, lane^32 the rest
-        float mx = fmaxf(s0[0], s1[0]);
+        // ---- online softmax in base 2; this lane holds half of its query's KT scores, lane^32 the rest
+        float mx = sc[0][0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+        for (int u = 0; u < NS; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[u][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0
         m_run = m_new;
         float psum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            s0[r] = __builtin_amdgcn_exp2f(s0[r] - m_new);
-            s1[r] = __builtin_amdgcn_exp2f(s1[r] - m_new);
-            psum += s0[r] + s1[r];
-        }
+        for (int u = 0; u < NS; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                sc[u][r] = __builtin_amdgcn_exp2f(sc[u][r] - m_new);
+                psum += sc[u][r];
+            }
         l_run = l_run * alpha + psum;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -145,17 +151,16 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_kernel(const float *__re
             o1[r] *= alpha;
         }
 
-        // ---- Oᵀ += Vᵀ Pᵀ : step r of sub-tile s contracts keys {key(r,0), key(r,1)}
+        // ---- Oᵀ += Vᵀ Pᵀ : step r of sub-tile u contracts keys {key(r,0), key(r,1)}
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int key = (r & 3) + 8 * (r >> 2) + 4 * lh;
-            const float va0 = sV[key * HD + l31], va1 = sV[key * HD + 32 + l31];
-            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va0, s0[r], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va1, s0[r], o1, 0, 0, 0);
-            const float vb0 = sV[(32 + key) * HD + l31], vb1 = sV[(32 + key) * HD + 32 + l31];
-            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vb0, s1[r], o0, 0, 0, 0);
-            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vb1, s1[r], o1, 0, 0, 0);
-        }
+        for (int u = 0; u < NS; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = 32 * u + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float v0 = sV[key * HD + l31], v1 = sV[key * HD + 32 + l31];
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, sc[u][r], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, sc[u][r], o1, 0, 0, 0);
+            }
     }
 
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
@@ -189,12 +194,19 @@ int attn_spatial(const float *qkv, float *out, int F, int N, int heads, hipStrea
     int nw = N > 64 ? 4 : (N > 32 ? 2 : 1);
     if (forced == 1 || forced == 2 || forced == 4) nw = forced;
     dim3 grid((unsigned)((long long)((N + nw * 32 - 1) / (nw * 32)) * heads * F));
-    if (nw == 4)
-        hipLaunchKernelGGL(attn_spatial_kernel<4>, grid, dim3(256), 0, st, qkv, out, N, heads);
+    static const int kt_forced = [] {
+        const char *e = getenv("EDV_ATTN_KT");
+        return e ? atoi(e) : 0;
+    }();
+    const int kt = kt_forced == 32 ? 32 : 64;  // measured equal at N = 1370 (283.7 vs 284.0 us), 64 slightly ahead at N = 4096
+    if (nw == 4 && kt == 32)
+        hipLaunchKernelGGL((attn_spatial_kernel<4, 32>), grid, dim3(256), 0, st, qkv, out, N, heads);
+    else if (nw == 4)
+        hipLaunchKernelGGL((attn_spatial_kernel<4, 64>), grid, dim3(256), 0, st, qkv, out, N, heads);
     else if (nw == 2)
-        hipLaunchKernelGGL(attn_spatial_kernel<2>, grid, dim3(128), 0, st, qkv, out, N, heads);
+        hipLaunchKernelGGL((attn_spatial_kernel<2, 32>), grid, dim3(128), 0, st, qkv, out, N, heads);
     else
-        hipLaunchKernelGGL(attn_spatial_kernel<1>, grid, dim3(64), 0, st, qkv, out, N, heads);
+        hipLaunchKernelGGL((attn_spatial_kernel<1, 32>), grid, dim3(64), 0, st, qkv, out, N, heads);
     EDV_LAUNCH_OK();
     return 0;
 }

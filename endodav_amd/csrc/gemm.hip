@@ -233,6 +233,14 @@ int gemm(const GemmDesc &d, hipStream_t st) {
         EDV_CHECK(d.R1 == nullptr && d.R2 == nullptr && d.P1 == nullptr, "pixel-shuffle store takes no residual");
     }
     EDV_CHECK(((uintptr_t)d.A % 16 == 0) && ((uintptr_t)d.W % 16 == 0), "A/W must be 16-byte aligned");
+    // LDS-DMA staging (gemm_dma.hip) is ahead on every shape the model produces (ViT-S T=8 +3.2 %, T=32 +2.7 %, ViT-B
+    // +2.7 %, ViT-L +2.2 % end to end: profiles/r01_gemm_tile_sweep.txt); the register-staged kernel below keeps the
+    // implicit-GEMM convolutions, K tails and narrow outputs.  EDV_GEMM_DMA=0 switches the DMA path off for A/B runs.
+    static const bool dma_on = [] {
+        const char *e = getenv("EDV_GEMM_DMA");
+        return !(e && atoi(e) == 0);
+    }();
+    if (dma_on && gemm_dma_supported(d) && d.N > 32) return gemm_dma(d, st);
     switch (pick_tile(d)) {
         case 0: return launch_tile<128, 128, 2, 2>(d, st);
         case 1: return launch_tile<128, 64, 2, 2>(d, st);

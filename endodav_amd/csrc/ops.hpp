@@ -49,6 +49,9 @@ struct GemmDesc {
     int ps_s = 0, ps_C = 0, ps_h = 0, ps_w = 0;
 };
 int gemm(const GemmDesc &d, hipStream_t st);
+// LDS-DMA staged variant (gemm_dma.hip): dense A, K % 32 == 0; picked by gemm() for small/medium grids.
+bool gemm_dma_supported(const GemmDesc &d);
+int gemm_dma(const GemmDesc &d, hipStream_t st);
 // Split-bf16 variant (gemm_sb.hip): same contract, fp32-equivalent accuracy from six bf16 MFMAs per product.
 bool gemm_sb_supported(const GemmDesc &d);
 int gemm_sb(const GemmDesc &d, hipStream_t st);

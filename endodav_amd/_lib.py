@@ -11,7 +11,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EDV_LIB_PATH") or os.path.join(_HERE, "lib", "libendodav_hip.so")  # override: experiments only
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 LORA_TYPES = {"none": 0, "lora": 1, "dvlora": 2, "ssb": 3, "dash": 4}
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_SIGMOID_NEG = 0, 1, 2, 3, 4
@@ -71,7 +71,8 @@ SIGNATURES = {
     "edv_conv3x3": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _fp, _fp, C.c_void_p]),
     "edv_pack_conv3x3": (C.c_int, [_fp, _fp, _i32, _i32, C.c_void_p]),
     "edv_conv_transpose": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
-    "edv_attn_spatial": (C.c_int, [_fp, _fp, _i32, _i32, _i32, C.c_void_p]),
+    "edv_attn_spatial_workspace": (C.c_size_t, [_i32, _i32, _i32]),
+    "edv_attn_spatial": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _fp, C.c_size_t, C.c_void_p]),
     "edv_attn_temporal": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
     "edv_groupnorm": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _f32, C.c_void_p]),
     "edv_geglu": (C.c_int, [_fp, _fp, _i64, _i32, C.c_void_p]),

@@ -73,8 +73,10 @@ int edv_conv_transpose(const float *x_dev, const float *w_dev, const float *b_de
     return gemm(g, (hipStream_t)stream);
 }
 
-int edv_attn_spatial(const float *qkv_dev, float *out_dev, int32_t F, int32_t N, int32_t heads, void *stream) {
-    return attn_spatial(qkv_dev, out_dev, F, N, heads, (hipStream_t)stream);
+size_t edv_attn_spatial_workspace(int32_t F, int32_t N, int32_t heads) { return attn_spatial_workspace(F, N, heads) * sizeof(float); }
+int edv_attn_spatial(const float *qkv_dev, float *out_dev, int32_t F, int32_t N, int32_t heads, float *workspace_dev, size_t workspace_bytes,
+                     void *stream) {
+    return attn_spatial(qkv_dev, out_dev, F, N, heads, workspace_dev, workspace_bytes / sizeof(float), (hipStream_t)stream);
 }
 
 int edv_attn_temporal(const float *qkv_dev, float *out_dev, int32_t B, int32_t T, int32_t P, int32_t C, int32_t heads, void *stream) {

@@ -15,10 +15,23 @@
 // feed the second product straight from the accumulator registers: the accumulator's row map
 // key = (r&3) + 8*(r>>2) + 4*(lane>>5) assigns register r of lane-half h exactly the k-slot h
 // of MFMA step r, so no data moves between the two products.
+//
+// Scheduling: persistent workgroups, data-parallel + stream-K hybrid.  A task = (frame, head, 128-query block) swept
+// over all key tiles; at T=8 ViT-S there are 528 of them for 512 co-resident workgroup slots (2 per CU), which as a
+// plain grid costs three task times where 2.06 are needed (81 TF/s measured vs 129 TF/s on a large grid).  So the
+// grid is exactly the number of co-resident slots G; every workgroup first runs floor(tasks / G) whole tasks, then the
+// tasks % G leftover tasks are cut along the KEY axis into G equal runs of key tiles.  A run that does not cover a whole
+// task leaves (unnormalised Oᵀ, running max, running sum) in a workspace slot — at most two per workgroup — and
+// attn_combine_kernel merges the pieces of each leftover task (the usual log-sum-exp merge, in base 2).
 #include <cmath>
 #include <cstdlib>
 
 #include "ops.hpp"
+
+// Timeline hook for scratch/ubench/attn_trace.hip (stamps per key tile); expands to nothing in the product build.
+#ifndef EDV_ATTN_STAMP
+#define EDV_ATTN_STAMP(slot)
+#endif
 
 namespace edv {
 namespace {
@@ -33,181 +46,334 @@ constexpr int KS = HD + 4;   // padded K row stride: 68r mod 64 = 4r -> conflict
 // KT keys per LDS tile (32 or 64).  32-key tiles halve the prefetch and score registers (159 instead of 198 per lane:
 // 3 instead of 2 waves per SIMD) but measured no faster, so 64 stays the default; EDV_ATTN_KT=32 selects the other.
 template <int NW, int KT>
-__global__ __launch_bounds__(NW * 64) void attn_spatial_kernel(const float *__restrict__ qkv, float *__restrict__ out, int N, int heads) {
+__global__ __launch_bounds__(NW * 64) void attn_spatial_kernel(const float *__restrict__ qkv, float *__restrict__ out, float *__restrict__ ws,
+                                                               int N, int heads, int whole_rounds, long long units, int chunk) {
     constexpr int QB = NW * 32;
     constexpr int NT = NW * 64;
+    constexpr int SLOTF = QB * (HD + 2);  // workspace slot: O [QB][64], m [QB], l [QB]
     __shared__ __attribute__((aligned(16))) float smem[KT * KS + KT * HD];
     float *sK = smem;
     float *sV = smem + KT * KS;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
-    // XCD-aware block -> (frame, head, query tile) map.  Workgroups b and b+8 share an XCD and its L2; the query
-    // tiles of one (frame, head) all sweep the same K/V, so hand each XCD a contiguous run of logical tiles
-    // (bijective for any grid size).  Measured: L2->fabric reads per launch 290 MB -> see profiles/.
+    // XCD-aware block -> logical id map.  Workgroups b and b+8 share an XCD and its L2; the query blocks of one
+    // (frame, head) all sweep the same K/V, so hand each XCD a contiguous run of logical ids = of tasks
+    // (bijective for any grid size).  Measured: L2->fabric reads per launch 307 MB -> 69 MB (profiles/).
     const int nq = (N + QB - 1) / QB;
+    const int G = gridDim.x;
     int bid = blockIdx.x;
     {
-        const int nblk = gridDim.x, q = nblk >> 3, r = nblk & 7, x = bid & 7, loc = bid >> 3;
+        const int q = G >> 3, r = G & 7, x = bid & 7, loc = bid >> 3;
         bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
     }
-    const int qt = bid % nq, fh = bid / nq;
-    const int head = fh % heads, frame = fh / heads;
     const int D = heads * HD, D3 = 3 * D;
-    const float *base = qkv + (long long)frame * N * D3 + head * HD;
-
-    const int qi = qt * QB + wave * 32 + l31;
-    const int qrow = qi < N ? qi : N - 1;
-
-    // Q fragment in permuted-k order: element e of qf[qq] is d = 8*qq + 4*lh + e
-    const float qscale = 0.125f * 1.44269504088896340736f;  // d^-0.5 (exact) * log2(e)
-    f32x4 qf[8];
-#pragma unroll
-    for (int qq = 0; qq < 8; ++qq) {
-        f32x4 v = *reinterpret_cast<const f32x4 *>(base + (long long)qrow * D3 + 8 * qq + 4 * lh);
-        qf[qq] = v * qscale;
-    }
-
-    f32x16 o0, o1;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
-    float m_run = -INFINITY, l_run = 0.f;
-
-    // staging slots: 16 float4 per 64-float row; thread -> (row sr + RS*i, chunk sc)
-    constexpr int RS = NT / 16, RI = KT / RS;  // rows per pass, passes
-    const int sc = tid & 15, sr = tid >> 4;
-    f32x4 rk[RI], rv[RI];
-    auto load_tile = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < RI; ++i) {
-            int kr = k0 + sr + RS * i;
-            kr = kr < N ? kr : N - 1;  // clamped rows are masked below
-            const float *p = base + (long long)kr * D3 + sc * 4;
-            rk[i] = *reinterpret_cast<const f32x4 *>(p + D);
-            rv[i] = *reinterpret_cast<const f32x4 *>(p + 2 * D);
-        }
-    };
-
     const int ntiles = (N + KT - 1) / KT;
-    load_tile(0);
-    for (int t = 0; t < ntiles; ++t) {
-        const int k0 = t * KT;
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < RI; ++i) {
-            *reinterpret_cast<f32x4 *>(&sK[(sr + RS * i) * KS + sc * 4]) = rk[i];
-            *reinterpret_cast<f32x4 *>(&sV[(sr + RS * i) * HD + sc * 4]) = rv[i];
-        }
-        __syncthreads();
-        if (t + 1 < ntiles) load_tile(k0 + KT);
+    const float qscale = 0.125f * 1.44269504088896340736f;  // d^-0.5 (exact) * log2(e)
+    constexpr int RS = NT / 16, RI = KT / RS;  // staging: rows per pass, passes (16 float4 per 64-float row)
+    const int sc = tid & 15, sr = tid >> 4;
 
-        // ---- Sᵀ = K Qᵀ : KT/32 sub-tiles of 32 keys
-        constexpr int NS = KT / 32;
-        f32x16 sc[NS];
-#pragma unroll
-        for (int u = 0; u < NS; ++u)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) sc[u][r] = 0.f;
+    // work list of this workgroup: whole_rounds whole tasks, then key-tile units [u, u_end) of the leftover tasks.
+    // (Fetching the next run's first K/V tile under the last tile of the current run was tried: no gain, and the extra
+    // control flow in the tile loop cost 3-4 % on every shape.)
+    const int task_l0 = whole_rounds * G;
+    long long u = (long long)bid * chunk;
+    const long long u_end = u + chunk < units ? u + chunk : units;
+    int round = 0, seg = 0;
+    for (;;) {
+        int task, kt0, kt1;
+        float *part = nullptr;
+        if (round < whole_rounds) {
+            task = round * G + bid;
+            kt0 = 0;
+            kt1 = ntiles;
+            ++round;
+        } else if (u < u_end) {
+            const int t = (int)(u / ntiles);
+            kt0 = (int)(u - (long long)t * ntiles);
+            const long long left = u_end - u;
+            kt1 = kt0 + left < ntiles ? kt0 + (int)left : ntiles;
+            task = task_l0 + t;
+            u += kt1 - kt0;
+            if (!(kt0 == 0 && kt1 == ntiles)) part = ws + ((long long)bid * 2 + seg) * SLOTF;
+            ++seg;  // slot 0 = the run holding this workgroup's first unit, slot 1 = the next task's head
+        } else {
+            break;
+        }
+        const int qt = task % nq, fh = task / nq;
+        const int head = fh % heads, frame = fh / heads;
+        const float *base = qkv + (long long)frame * N * D3 + head * HD;
+        const int qi = qt * QB + wave * 32 + l31;
+        const int qrow = qi < N ? qi : N - 1;
+
+        // Q fragment in permuted-k order: element e of qf[qq] is d = 8*qq + 4*lh + e
+        f32x4 qf[8];
 #pragma unroll
         for (int qq = 0; qq < 8; ++qq) {
-            f32x4 kf[NS];
-#pragma unroll
-            for (int u = 0; u < NS; ++u) kf[u] = *reinterpret_cast<const f32x4 *>(&sK[(32 * u + l31) * KS + 8 * qq + 4 * lh]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int u = 0; u < NS; ++u) sc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[u][e], qf[qq][e], sc[u], 0, 0, 0);
+            f32x4 v = *reinterpret_cast<const f32x4 *>(base + (long long)qrow * D3 + 8 * qq + 4 * lh);
+            qf[qq] = v * qscale;
         }
-        if (k0 + KT > N) {  // last tile: keys past the sequence end
+
+        f32x16 o0, o1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+        float m_run = -INFINITY, l_run = 0.f;
+
+        f32x4 rk[RI], rv[RI];
+        auto load_tile = [&](int k0) {
+#pragma unroll
+            for (int i = 0; i < RI; ++i) {
+                int kr = k0 + sr + RS * i;
+                kr = kr < N ? kr : N - 1;  // clamped rows are masked below
+                const float *p = base + (long long)kr * D3 + sc * 4;
+                rk[i] = *reinterpret_cast<const f32x4 *>(p + D);
+                rv[i] = *reinterpret_cast<const f32x4 *>(p + 2 * D);
+            }
+        };
+
+        load_tile(kt0 * KT);
+        EDV_ATTN_STAMP(0);
+        for (int t = kt0; t < kt1; ++t) {
+            const int k0 = t * KT;
+            EDV_ATTN_STAMP(1 + t - kt0);
+            __syncthreads();  // also fences the previous run's last tile
+#pragma unroll
+            for (int i = 0; i < RI; ++i) {
+                *reinterpret_cast<f32x4 *>(&sK[(sr + RS * i) * KS + sc * 4]) = rk[i];
+                *reinterpret_cast<f32x4 *>(&sV[(sr + RS * i) * HD + sc * 4]) = rv[i];
+            }
+            __syncthreads();
+            if (t + 1 < kt1) load_tile(k0 + KT);
+
+            // ---- Sᵀ = K Qᵀ : KT/32 sub-tiles of 32 keys
+            constexpr int NS = KT / 32;
+            f32x16 sc[NS];
 #pragma unroll
             for (int u = 0; u < NS; ++u)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (k0 + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * lh >= N) sc[u][r] = -INFINITY;
-        }
+                for (int r = 0; r < 16; ++r) sc[u][r] = 0.f;
+#pragma unroll
+            for (int qq = 0; qq < 8; ++qq) {
+                f32x4 kf[NS];
+#pragma unroll
+                for (int u = 0; u < NS; ++u) kf[u] = *reinterpret_cast<const f32x4 *>(&sK[(32 * u + l31) * KS + 8 * qq + 4 * lh]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int u = 0; u < NS; ++u) sc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[u][e], qf[qq][e], sc[u], 0, 0, 0);
+            }
+            if (k0 + KT > N) {  // last tile: keys past the sequence end
+#pragma unroll
+                for (int u = 0; u < NS; ++u)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (k0 + 32 * u + (r & 3) + 8 * (r >> 2) + 4 * lh >= N) sc[u][r] = -INFINITY;
+            }
 
-        // ---- online softmax in base 2; this lane holds half of its query's KT scores, lane^32 the rest
-        float mx = sc[0][0];
+            // ---- online softmax in base 2; this lane holds half of its query's KT scores, lane^32 the rest
+            float mx = sc[0][0];
 #pragma unroll
-        for (int u = 0; u < NS; ++u)
+            for (int u = 0; u < NS; ++u)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[u][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0
-        m_run = m_new;
-        float psum = 0.f;
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[u][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // first tile: exp2(-inf) = 0
+            m_run = m_new;
+            float psum = 0.f;
 #pragma unroll
-        for (int u = 0; u < NS; ++u)
+            for (int u = 0; u < NS; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    sc[u][r] = __builtin_amdgcn_exp2f(sc[u][r] - m_new);
+                    psum += sc[u][r];
+                }
+            l_run = l_run * alpha + psum;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                sc[u][r] = __builtin_amdgcn_exp2f(sc[u][r] - m_new);
-                psum += sc[u][r];
+                o0[r] *= alpha;
+                o1[r] *= alpha;
             }
-        l_run = l_run * alpha + psum;
+
+            // ---- Oᵀ += Vᵀ Pᵀ : step r of sub-tile u contracts keys {key(r,0), key(r,1)}
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            o0[r] *= alpha;
-            o1[r] *= alpha;
+            for (int u = 0; u < NS; ++u)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = 32 * u + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const float v0 = sV[key * HD + l31], v1 = sV[key * HD + 32 + l31];
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, sc[u][r], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, sc[u][r], o1, 0, 0, 0);
+                }
         }
 
-        // ---- Oᵀ += Vᵀ Pᵀ : step r of sub-tile u contracts keys {key(r,0), key(r,1)}
-#pragma unroll
-        for (int u = 0; u < NS; ++u)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = 32 * u + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float v0 = sV[key * HD + l31], v1 = sV[key * HD + 32 + l31];
-                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v0, sc[u][r], o0, 0, 0, 0);
-                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v1, sc[u][r], o1, 0, 0, 0);
+        EDV_ATTN_STAMP(1 + kt1 - kt0);
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        float inv = 1.0f / l_tot;
+        float *orow = nullptr;
+        if (part) {  // a piece of a split task: unnormalised, merged by attn_combine_kernel
+            const int ql = wave * 32 + l31;
+            orow = part + ql * HD;
+            inv = 1.0f;
+            if (lh == 0) {
+                part[QB * HD + ql] = m_run;
+                part[QB * HD + QB + ql] = l_tot;
             }
-    }
-
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.0f / l_tot;
-    if (qi < N) {
-        float *orow = out + ((long long)frame * N + qi) * D + head * HD;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 are d = 8g + 4*lh + {0..3}
-            f32x4 a = {o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
-            f32x4 b = {o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
-            *reinterpret_cast<f32x4 *>(orow + 8 * g + 4 * lh) = a;
-            *reinterpret_cast<f32x4 *>(orow + 32 + 8 * g + 4 * lh) = b;
+        } else if (qi < N) {
+            orow = out + ((long long)frame * N + qi) * D + head * HD;
         }
+        if (orow) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 are d = 8g + 4*lh + {0..3}
+                f32x4 a = {o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
+                f32x4 b = {o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
+                *reinterpret_cast<f32x4 *>(orow + 8 * g + 4 * lh) = a;
+                *reinterpret_cast<f32x4 *>(orow + 32 + 8 * g + 4 * lh) = b;
+            }
+        }
+        EDV_ATTN_STAMP(2 + kt1 - kt0);
     }
 }
 
-}  // namespace
+// Merge of the pieces of every split (leftover) task.  Piece list of leftover task t: the workgroups whose unit runs
+// [g*chunk, (g+1)*chunk) intersect [t*ntiles, (t+1)*ntiles); a workgroup's piece sits in its slot 0 when its first unit
+// lies in this task, else in slot 1.  Thread = (query, 16-byte output chunk); 16 queries per 256-thread block.
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restrict__ ws, float *__restrict__ out, int N, int heads, int QB, int ntiles,
+                                                           int task_l0, long long units, int chunk) {
+    const int t = blockIdx.x;
+    const int ql = blockIdx.y * 16 + (threadIdx.x >> 4), ch = threadIdx.x & 15;
+    const long long ub = (long long)t * ntiles, ue = ub + ntiles;
+    const int g0 = (int)(ub / chunk), g1 = (int)((ue - 1) / chunk);
+    if (g0 == g1 && (long long)g0 * chunk <= ub && (long long)(g0 + 1) * chunk >= ue) return;  // ran whole, already stored
+    const int nq = (N + QB - 1) / QB;
+    const int task = task_l0 + t;
+    const int qt = task % nq, fh = task / nq;
+    const int head = fh % heads, frame = fh / heads;
+    const int qi = qt * QB + ql;
+    if (qi >= N) return;
+    const long long slotf = (long long)QB * (HD + 2);
+    // two sweeps, loads batched four pieces at a time (the piece count is small but the loads are long-latency)
+    auto slot_of = [&](int g) { return ws + ((long long)g * 2 + ((long long)g * chunk >= ub ? 0 : 1)) * slotf; };
+    float M = -INFINITY;
+    for (int g = g0; g <= g1; g += 4) {
+        float mi[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mi[j] = slot_of(g + j <= g1 ? g + j : g1)[QB * HD + ql];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) M = fmaxf(M, mi[j]);
+    }
+    float lsum = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int g = g0; g <= g1; g += 4) {
+        float mi[4], li[4];
+        f32x4 o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float *part = slot_of(g + j <= g1 ? g + j : g1);
+            mi[j] = part[QB * HD + ql];
+            li[j] = part[QB * HD + QB + ql];
+            o[j] = *reinterpret_cast<const f32x4 *>(part + ql * HD + ch * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float w = g + j <= g1 ? __builtin_amdgcn_exp2f(mi[j] - M) : 0.f;
+            acc += o[j] * w;
+            lsum += li[j] * w;
+        }
+    }
+    const float inv = 1.0f / lsum;
+    *reinterpret_cast<f32x4 *>(out + ((long long)frame * N + qi) * (heads * HD) + head * HD + ch * 4) = acc * inv;
+}
 
-int attn_spatial(const float *qkv, float *out, int F, int N, int heads, hipStream_t st) {
-    EDV_CHECK(qkv && out, "null operand");
-    EDV_CHECK(F > 0 && N > 0 && heads > 0, "empty problem");
-    EDV_CHECK((long long)F * heads * ((N + 31) / 32) < (1ll << 31), "grid limits");
-    EDV_CHECK(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 16 == 0), "16-byte alignment");
-    // 4 waves (128 queries) per workgroup share each staged K/V tile.  The 2- and 1-wave variants give a finer
-    // grid but cost registers (195 / 256 VGPRs) and measured slower on every shape tried (T=8: 79.9 vs 78.6 vs
-    // 68.5 TF/s); they are kept for sequences shorter than one 128-query block and for experiments.
+struct AttnPlan {
+    int nw, kt, grid, whole_rounds, chunk, ntasks, ntiles, leftover;
+    long long units;
+    size_t ws_floats;
+};
+
+template <int NW, int KT>
+int resident_slots() {
+    static const int slots = [] {
+        int dev = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, attn_spatial_kernel<NW, KT>, NW * 64, 0) != hipSuccess) return 0;
+        return cus * per_cu;
+    }();
+    return slots;
+}
+
+int make_plan(int F, int N, int heads, AttnPlan *p) {
+    // 4 waves (128 queries) per workgroup share each staged K/V tile.  The 2- and 1-wave variants cost registers
+    // (195 / 256 VGPRs) and measured slower on every shape tried (T=8: 79.9 vs 78.6 vs 68.5 TF/s); they are kept for
+    // sequences shorter than one 128-query block and for experiments.
     static const int forced = [] {
         const char *e = getenv("EDV_ATTN_WAVES");
         return e ? atoi(e) : 0;
     }();
-    int nw = N > 64 ? 4 : (N > 32 ? 2 : 1);
-    if (forced == 1 || forced == 2 || forced == 4) nw = forced;
-    dim3 grid((unsigned)((long long)((N + nw * 32 - 1) / (nw * 32)) * heads * F));
     static const int kt_forced = [] {
         const char *e = getenv("EDV_ATTN_KT");
         return e ? atoi(e) : 0;
     }();
-    const int kt = kt_forced == 32 ? 32 : 64;  // measured equal at N = 1370 (283.7 vs 284.0 us), 64 slightly ahead at N = 4096
-    if (nw == 4 && kt == 32)
-        hipLaunchKernelGGL((attn_spatial_kernel<4, 32>), grid, dim3(256), 0, st, qkv, out, N, heads);
-    else if (nw == 4)
-        hipLaunchKernelGGL((attn_spatial_kernel<4, 64>), grid, dim3(256), 0, st, qkv, out, N, heads);
-    else if (nw == 2)
-        hipLaunchKernelGGL((attn_spatial_kernel<2, 32>), grid, dim3(128), 0, st, qkv, out, N, heads);
+    static const int plain = [] {
+        const char *e = getenv("EDV_ATTN_PLAIN");  // 1: one workgroup per task (the pre-stream-K grid), for A/B runs
+        return e ? atoi(e) : 0;
+    }();
+    int nw = N > 64 ? 4 : (N > 32 ? 2 : 1);
+    if (forced == 1 || forced == 2 || forced == 4) nw = forced;
+    p->nw = nw;
+    p->kt = nw == 4 ? (kt_forced == 32 ? 32 : 64) : 32;  // 32-key tiles measured equal at N = 1370 (283.7 vs 284.0 us)
+    const int slots = nw == 4 ? (p->kt == 64 ? resident_slots<4, 64>() : resident_slots<4, 32>()) : nw == 2 ? resident_slots<2, 32>() : resident_slots<1, 32>();
+    EDV_CHECK(slots > 0, "occupancy query failed");
+    const long long ntasks = (long long)F * heads * ((N + nw * 32 - 1) / (nw * 32));
+    EDV_CHECK(ntasks < (1ll << 31), "grid limits");
+    p->ntasks = (int)ntasks;
+    p->ntiles = (N + p->kt - 1) / p->kt;
+    if (plain) {
+        p->grid = p->ntasks; p->whole_rounds = 1; p->leftover = 0; p->units = 0; p->chunk = 1; p->ws_floats = 0;
+        return 0;
+    }
+    p->whole_rounds = p->ntasks / slots;
+    p->leftover = p->ntasks - p->whole_rounds * slots;
+    p->units = (long long)p->leftover * p->ntiles;
+    p->chunk = p->units ? (int)((p->units + slots - 1) / slots) : 1;
+    p->grid = p->whole_rounds ? slots : (int)((p->units + p->chunk - 1) / p->chunk);
+    const int split_wgs = (int)((p->units + p->chunk - 1) / p->chunk);
+    p->ws_floats = (size_t)split_wgs * 2 * (size_t)(nw * 32) * (HD + 2);
+    return 0;
+}
+
+}  // namespace
+
+size_t attn_spatial_workspace(int F, int N, int heads) {
+    AttnPlan p;
+    if (F <= 0 || N <= 0 || heads <= 0 || make_plan(F, N, heads, &p)) return 0;
+    return p.ws_floats;
+}
+
+int attn_spatial(const float *qkv, float *out, int F, int N, int heads, float *ws, size_t ws_floats, hipStream_t st) {
+    EDV_CHECK(qkv && out, "null operand");
+    EDV_CHECK(F > 0 && N > 0 && heads > 0, "empty problem");
+    EDV_CHECK(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 16 == 0), "16-byte alignment");
+    AttnPlan p;
+    EDV_TRY(make_plan(F, N, heads, &p));
+    EDV_CHECK(p.ws_floats == 0 || (ws && ws_floats >= p.ws_floats && (uintptr_t)ws % 16 == 0), "attention workspace too small (attn_spatial_workspace)");
+    dim3 grid((unsigned)p.grid);
+    if (p.nw == 4 && p.kt == 32)
+        hipLaunchKernelGGL((attn_spatial_kernel<4, 32>), grid, dim3(256), 0, st, qkv, out, ws, N, heads, p.whole_rounds, p.units, p.chunk);
+    else if (p.nw == 4)
+        hipLaunchKernelGGL((attn_spatial_kernel<4, 64>), grid, dim3(256), 0, st, qkv, out, ws, N, heads, p.whole_rounds, p.units, p.chunk);
+    else if (p.nw == 2)
+        hipLaunchKernelGGL((attn_spatial_kernel<2, 32>), grid, dim3(128), 0, st, qkv, out, ws, N, heads, p.whole_rounds, p.units, p.chunk);
     else
-        hipLaunchKernelGGL((attn_spatial_kernel<1, 32>), grid, dim3(64), 0, st, qkv, out, N, heads);
+        hipLaunchKernelGGL((attn_spatial_kernel<1, 32>), grid, dim3(64), 0, st, qkv, out, ws, N, heads, p.whole_rounds, p.units, p.chunk);
     EDV_LAUNCH_OK();
+    if (p.leftover) {
+        const int QB = p.nw * 32;
+        hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)p.leftover, (unsigned)(QB / 16)), dim3(256), 0, st, ws, out, N, heads, QB, p.ntiles,
+                           p.whole_rounds * p.grid, p.units, p.chunk);
+        EDV_LAUNCH_OK();
+    }
     return 0;
 }
 

@@ -468,6 +468,8 @@ struct Run {
         float *cols, *xt, *xn, *qkv, *att, *hid;
         float *tap[4], *tapcls[4];
         const float *pos;
+        float *attws;      // attention split workspace, one region of attws_each floats per encoder stream
+        size_t attws_each;
     };
     int ensure_streams() {
         if (c->sub[0]) return 0;
@@ -479,7 +481,7 @@ struct Run {
         return 0;
     }
     // encoder on frames [f0, f0 + nf) enqueued on stream s (vision_transformer.py:279-289 + :317-321)
-    int encoder_range(const EncBufs &eb, const float *x, int f0, int nf, int H, int W, hipStream_t s) {
+    int encoder_range(const EncBufs &eb, const float *x, int f0, int nf, int H, int W, hipStream_t s, int lane = 0) {
         st = s;
         F = nf;
         const long long MT = (long long)nf * ntok;
@@ -524,7 +526,7 @@ struct Run {
             EDV_TRY(linear(xn, MT, D, w, 3 * D, b, qkv));
             {
                 Bracket b_(c, KC_ATTN_SPATIAL, st);
-                EDV_TRY(attn_spatial(qkv, att, F, ntok, heads, st));
+                EDV_TRY(attn_spatial(qkv, att, F, ntok, heads, eb.attws + (size_t)lane * eb.attws_each, eb.attws_each, st));
             }
             c->launches++;
             EDV_TRY(param(bp + ".attn.proj.weight", &w));
@@ -580,12 +582,21 @@ struct Run {
 
         const float *pos;
         EDV_TRY(pos_table(&pos));
-        EncBufs eb{cols, xt, xn, qkv, att, hid, {tap[0], tap[1], tap[2], tap[3]}, {tapcls[0], tapcls[1], tapcls[2], tapcls[3]}, pos};
         // Frames are independent in the encoder: with two internal streams the two halves of the batch run as
         // concurrent kernels, so workgroups of different kernels (one half's attention, the other's GEMM) co-reside
         // on the CUs and fill each other's stalls and grid tails.  The head needs all T frames again (temporal attention).
         int nstreams = (c->enc_streams > 1 && !c->capture) ? (c->enc_streams > 4 ? 4 : c->enc_streams) : 1;
         if (nstreams > F) nstreams = F;
+        size_t attws_each = 0;  // the largest split workspace any stream's share of the frames needs
+        for (int h = 0, f0 = 0; h < nstreams; ++h) {
+            const int nf = (F - f0) / (nstreams - h);
+            const size_t need = (attn_spatial_workspace(nf, ntok, heads) + 3) & ~(size_t)3;
+            attws_each = need > attws_each ? need : attws_each;
+            f0 += nf;
+        }
+        float *attws = nullptr;
+        if (attws_each) EDV_TRY(wsbuf("attws", attws_each * nstreams, &attws));
+        EncBufs eb{cols, xt, xn, qkv, att, hid, {tap[0], tap[1], tap[2], tap[3]}, {tapcls[0], tapcls[1], tapcls[2], tapcls[3]}, pos, attws, attws_each};
         if (nstreams == 1) {
             EDV_TRY(encoder_range(eb, x, 0, F, H, W, st));
         } else {
@@ -597,7 +608,7 @@ struct Run {
             for (int h = 0; h < nstreams; ++h) {
                 const int nf = (Fall - f0) / (nstreams - h);  // even split of the remaining frames
                 EDV_HIP(hipStreamWaitEvent(c->sub[h], c->ev_fork, 0));
-                const int rc = encoder_range(eb, x, f0, nf, H, W, c->sub[h]);
+                const int rc = encoder_range(eb, x, f0, nf, H, W, c->sub[h], h);
                 st = user; F = Fall;
                 if (rc) return rc;
                 EDV_HIP(hipEventRecord(c->ev_join[h], c->sub[h]));

@@ -26,7 +26,7 @@ namespace {
 constexpr int BK = 32;
 constexpr int LS = BK + 4;  // padded LDS row stride (floats)
 
-template <int BM, int BN, int WGM, int WGN, int LOADER, int STORE>
+template <int BM, int BN, int WGM, int WGN, int LOADER, int STORE, int EP>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc g) {
     constexpr int WTM = BM / WGM, WTN = BN / WGN;
     constexpr int FM = WTM / 32, FN = WTN / 32;
@@ -118,6 +118,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc g) {
         }
     };
 
+    EpiCols<FN> cols;
+    if (EP != 0) cols = gemm_epilogue_prefetch<FN>(g, n0, wn * WTN, l31);
     f32x16 acc[FM][FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i)
@@ -179,20 +181,42 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmDesc g) {
         __syncthreads();
     }
 
-    gemm_epilogue<FM, FN, STORE>(g, acc, m0, n0, wm * WTM, wn * WTN, l31, lh);
+    gemm_epilogue_ep<FM, FN, STORE, EP>(g, acc, cols, m0, n0, wm * WTM, wn * WTN, l31, lh);
 }
 
-template <int BM, int BN, int WGM, int WGN>
+// FASTEP: also instantiate the compact epilogues (gemm_common.hpp); the experiment-only wide tiles keep the general one.
+template <int BM, int BN, int WGM, int WGN, int LOADER, bool FASTEP>
+void launch_rows(const GemmDesc &d, dim3 grid, hipStream_t st) {
+    const dim3 block(256);
+    const int ep = FASTEP ? epilogue_kind(d) : 0;
+    if constexpr (FASTEP) {
+        if (ep == 1) {
+            hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, LOADER, STORE_ROWS, 1>), grid, block, 0, st, d);
+            return;
+        }
+        if (ep == 2) {
+            hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, LOADER, STORE_ROWS, 2>), grid, block, 0, st, d);
+            return;
+        }
+        if (ep == 3) {
+            hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, LOADER, STORE_ROWS, 3>), grid, block, 0, st, d);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, LOADER, STORE_ROWS, 0>), grid, block, 0, st, d);
+}
+
+template <int BM, int BN, int WGM, int WGN, bool FASTEP>
 int launch_tile(const GemmDesc &d, hipStream_t st) {
     const long long tiles = ((d.M + BM - 1) / BM) * (long long)((d.N + BN - 1) / BN);
     EDV_CHECK(tiles > 0 && tiles < (1ll << 31), "bad grid");
     dim3 grid((unsigned)tiles), block(256);
     if (d.loader == LOAD_DENSE && d.store == STORE_ROWS)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, LOAD_DENSE, STORE_ROWS>), grid, block, 0, st, d);
+        launch_rows<BM, BN, WGM, WGN, LOAD_DENSE, FASTEP>(d, grid, st);
     else if (d.loader == LOAD_CONV3 && d.store == STORE_ROWS)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, LOAD_CONV3, STORE_ROWS>), grid, block, 0, st, d);
+        launch_rows<BM, BN, WGM, WGN, LOAD_CONV3, FASTEP>(d, grid, st);
     else if (d.loader == LOAD_DENSE && d.store == STORE_SHUFFLE)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, LOAD_DENSE, STORE_SHUFFLE>), grid, block, 0, st, d);
+        hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, LOAD_DENSE, STORE_SHUFFLE, 0>), grid, block, 0, st, d);
     else
         EDV_CHECK(false, "unsupported loader/store combination");
     EDV_LAUNCH_OK();
@@ -242,10 +266,10 @@ int gemm(const GemmDesc &d, hipStream_t st) {
     }();
     if (dma_on && gemm_dma_supported(d) && d.N > 32) return gemm_dma(d, st);
     switch (pick_tile(d)) {
-        case 0: return launch_tile<128, 128, 2, 2>(d, st);
-        case 1: return launch_tile<128, 64, 2, 2>(d, st);
-        case 2: return launch_tile<128, 32, 4, 1>(d, st);
-        default: return launch_tile<64, 64, 2, 2>(d, st);
+        case 0: return launch_tile<128, 128, 2, 2, false>(d, st);
+        case 1: return launch_tile<128, 64, 2, 2, false>(d, st);
+        case 2: return launch_tile<128, 32, 4, 1, true>(d, st);
+        default: return launch_tile<64, 64, 2, 2, true>(d, st);
     }
 }
 

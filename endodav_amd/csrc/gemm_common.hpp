@@ -64,4 +64,92 @@ __device__ __forceinline__ void gemm_epilogue(const GemmDesc &g, f32x16 (&acc)[F
     }
 }
 
+
+// ---- compact epilogue for the common case -----------------------------------------------------------------------------
+// The general epilogue above unrolls 16 rows x every optional feature (row maps with 64-bit divisions, P1, a runtime
+// activation switch with an inlined erff per row): ~11 000 instructions, more than the 64 KB instruction cache two CUs
+// share.  A workgroup timeline (scratch/ubench/gemm_trace.hip) showed 7.8 us of a 27 us workgroup life inside it.  Every
+// encoder linear and every convolution needs only: identity row maps, no P1, a compile-time activation.
+//   EP = 0: general;  EP = 1 + ACT (ACT_NONE / ACT_GELU / ACT_RELU): fast.
+inline int epilogue_kind(const GemmDesc &d) {
+    if (d.store != STORE_ROWS || d.P1 || d.c_map.period != 0 || (d.R1 && d.r1_map.period != 0)) return 0;
+    if (d.act != ACT_NONE && d.act != ACT_GELU && d.act != ACT_RELU) return 0;
+    return 1 + d.act;
+}
+
+// Per-column epilogue operands, fetched BEFORE the k loop: at the end of the loop the load would queue behind the
+// other workgroups' tile traffic and its latency would be fully exposed.
+#ifndef EDV_EPI_STORE_COND
+#define EDV_EPI_STORE_COND  // ablation hook of scratch/ubench/gemm_trace.hip; empty in the product build
+#endif
+template <int FN>
+struct EpiCols {
+    float bias[FN], gam[FN];
+};
+template <int FN>
+__device__ __forceinline__ EpiCols<FN> gemm_epilogue_prefetch(const GemmDesc &g, int n0, int wcol, int l31) {
+    EpiCols<FN> c;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        int n = n0 + wcol + j * 32 + l31;
+        n = n < g.N ? n : g.N - 1;
+        c.bias[j] = g.bias ? g.bias[n] : 0.f;
+        c.gam[j] = g.gamma ? g.gamma[n] : 1.f;
+    }
+    return c;
+}
+
+template <int FM, int FN, int ACT>
+__device__ __forceinline__ void gemm_epilogue_fast(const GemmDesc &g, f32x16 (&acc)[FM][FN], const EpiCols<FN> &cols, long long m0, int n0, int wrow,
+                                                   int wcol, int l31, int lh) {
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wcol + j * 32 + l31;
+        if (n >= g.N) continue;
+        const float bias = cols.bias[j], gam = cols.gam[j];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const long long mb = m0 + wrow + i * 32 + 4 * lh;  // row of register r: mb + (r&3) + 8*(r>>2)
+            const int left = (int)(g.M - mb < 32 ? g.M - mb : 32);
+            float res[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) res[r] = 0.f;
+            if (g.R1) {
+                const float *rp = g.R1 + mb * g.ldr1 + n;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    if (dr < left) res[r] = rp[(long long)dr * g.ldr1];
+                }
+            }
+            if (g.R2) {
+                const float *rp = g.R2 + mb * g.ldr2 + n;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int dr = (r & 3) + 8 * (r >> 2);
+                    if (dr < left) res[r] += rp[(long long)dr * g.ldr2];
+                }
+            }
+            float *cp = g.C + mb * g.ldc + n;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dr = (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r] + bias;
+                if (ACT == ACT_GELU) v = gelu_erf(v);
+                if (ACT == ACT_RELU) v = fmaxf(v, 0.0f);
+                if (dr < left EDV_EPI_STORE_COND) cp[(long long)dr * g.ldc] = v * gam + res[r];
+            }
+        }
+    }
+}
+
+template <int FM, int FN, int STORE, int EP>
+__device__ __forceinline__ void gemm_epilogue_ep(const GemmDesc &g, f32x16 (&acc)[FM][FN], const EpiCols<FN> &cols, long long m0, int n0, int wrow,
+                                                 int wcol, int l31, int lh) {
+    if constexpr (EP == 0)
+        gemm_epilogue<FM, FN, STORE>(g, acc, m0, n0, wrow, wcol, l31, lh);
+    else
+        gemm_epilogue_fast<FM, FN, EP - 1>(g, acc, cols, m0, n0, wrow, wcol, l31, lh);
+}
+
 }  // namespace edv

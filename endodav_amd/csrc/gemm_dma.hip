@@ -17,16 +17,22 @@
 // caps it near 100 TF/s (register staging: 117), a regime the model does not reach with its K <= 4096, N <= 4096.
 #include "gemm_common.hpp"
 
+// Timeline hook for scratch/ubench/gemm_trace.hip; expands to nothing in the product build.
+#ifndef EDV_GEMM_STAMP
+#define EDV_GEMM_STAMP(slot)
+#endif
+
 namespace edv {
 namespace {
 
 constexpr int DBK = 32, DBM = 64, DBN = 64;
 constexpr int DSTAGE = (DBM + DBN) * DBK;  // floats per stage (16 KB)
 
-template <int STORE>
+template <int STORE, int EP>
 __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g) {
     __shared__ __attribute__((aligned(16))) float smem[2 * DSTAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    EDV_GEMM_STAMP(0);
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (g.N + DBN - 1) / DBN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
@@ -59,6 +65,8 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g) {
         }
     };
 
+    EpiCols<1> cols;
+    if (EP != 0) cols = gemm_epilogue_prefetch<1>(g, n0, wn * 32, l31);
     f32x16 acc[1][1];
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
@@ -67,8 +75,10 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g) {
     const int nkt = g.K / DBK;
 
     issue(0, 0);
+    EDV_GEMM_STAMP(1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    EDV_GEMM_STAMP(2);
     for (int kt = 0; kt < nkt; ++kt) {
         const int st = kt & 1;
         if (kt + 1 < nkt) issue(kt + 1, st ^ 1);  // the other stage was last read in iteration kt-1 (barrier passed)
@@ -86,7 +96,9 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     }
-    gemm_epilogue<1, 1, STORE>(g, acc, m0, n0, wm * 32, wn * 32, l31, lh);
+    EDV_GEMM_STAMP(3);
+    gemm_epilogue_ep<1, 1, STORE, EP>(g, acc, cols, m0, n0, wm * 32, wn * 32, l31, lh);
+    EDV_GEMM_STAMP(4);
 }
 
 }  // namespace
@@ -107,10 +119,16 @@ int gemm_dma(const GemmDesc &d, hipStream_t st) {
     const long long tiles = ((d.M + DBM - 1) / DBM) * (long long)((d.N + DBN - 1) / DBN);
     EDV_CHECK(tiles > 0 && tiles < (1ll << 31), "bad grid");
     dim3 grid((unsigned)tiles), block(256);
-    if (d.store == STORE_ROWS)
-        hipLaunchKernelGGL(gemm_dma_kernel<STORE_ROWS>, grid, block, 0, st, d);
-    else
-        hipLaunchKernelGGL(gemm_dma_kernel<STORE_SHUFFLE>, grid, block, 0, st, d);
+    if (d.store == STORE_SHUFFLE) {
+        hipLaunchKernelGGL((gemm_dma_kernel<STORE_SHUFFLE, 0>), grid, block, 0, st, d);
+    } else {
+        switch (epilogue_kind(d)) {
+            case 1: hipLaunchKernelGGL((gemm_dma_kernel<STORE_ROWS, 1>), grid, block, 0, st, d); break;
+            case 2: hipLaunchKernelGGL((gemm_dma_kernel<STORE_ROWS, 2>), grid, block, 0, st, d); break;
+            case 3: hipLaunchKernelGGL((gemm_dma_kernel<STORE_ROWS, 3>), grid, block, 0, st, d); break;
+            default: hipLaunchKernelGGL((gemm_dma_kernel<STORE_ROWS, 0>), grid, block, 0, st, d); break;
+        }
+    }
     EDV_LAUNCH_OK();
     return 0;
 }

@@ -62,7 +62,8 @@ const char *gemm_kernel_name(const GemmDesc &d);
 // ------------------------------------------------------------------------------------------
 // attention (attn_spatial.hip, temporal.hip)
 // ------------------------------------------------------------------------------------------
-int attn_spatial(const float *qkv, float *out, int F, int N, int heads, hipStream_t st);
+size_t attn_spatial_workspace(int F, int N, int heads);  // floats
+int attn_spatial(const float *qkv, float *out, int F, int N, int heads, float *ws, size_t ws_floats, hipStream_t st);
 int attn_temporal(const float *qkv, float *out, int B, int T, int P, int C, int heads, hipStream_t st);
 int geglu(const float *x, float *y, long long M, int inner, hipStream_t st);
 

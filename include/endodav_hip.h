@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EDV_ABI_VERSION 2
+#define EDV_ABI_VERSION 3
 
 enum edv_lora_type { EDV_LORA_NONE = 0, EDV_LORA_LORA = 1, EDV_LORA_DVLORA = 2, EDV_LORA_SSB = 3, EDV_LORA_DASH = 4 };
 
@@ -139,8 +139,13 @@ int edv_conv3x3(const float *x_dev, const float *wpacked_dev, const float *bias_
 int edv_pack_conv3x3(const float *w_dev, float *wpacked_dev, int32_t Cout, int32_t Cin, void *stream);
 
 /* Encoder self-attention, layers/attention.py:56-69: qkv [F*N, 3*heads*64] as produced by the
- * qkv linear (columns ordered [3][heads][64]) -> out [F*N, heads*64]. */
-int edv_attn_spatial(const float *qkv_dev, float *out_dev, int32_t F, int32_t N, int32_t heads, void *stream);
+ * qkv linear (columns ordered [3][heads][64]) -> out [F*N, heads*64].  The kernel runs as persistent workgroups
+ * that split the last, partial round of (frame, head, query-block) tasks along the key axis; the pieces meet in a
+ * device workspace of edv_attn_spatial_workspace(F, N, heads) BYTES (0 when nothing is split; 16-byte aligned,
+ * owned by the caller, one per concurrently running call). */
+size_t edv_attn_spatial_workspace(int32_t F, int32_t N, int32_t heads);
+int edv_attn_spatial(const float *qkv_dev, float *out_dev, int32_t F, int32_t N, int32_t heads, float *workspace_dev,
+                     size_t workspace_bytes, void *stream);
 
 /* Temporal attention core, motion_module.py:230-297 + attention.py:182-211: qkv [B*T*P, 3C]
  * (q|k|v per row, 8 heads), softmax over the T frames of each pixel -> out [B*T*P, C]. */

@@ -49,7 +49,9 @@ def gemm_sb(M, N, K, act=0, res=False, label=""):
 def attn(F, N, heads):
     qkv = torch.randn(F * N, 3 * heads * 64, device=dev)
     o = torch.empty(F * N, heads * 64, device=dev)
-    t = timeit(lambda: _lib.check(lib.edv_attn_spatial(qkv.data_ptr(), o.data_ptr(), F, N, heads, st())))
+    nb = lib.edv_attn_spatial_workspace(F, N, heads)
+    ws = torch.empty(max(nb // 4, 4), device=dev)
+    t = timeit(lambda: _lib.check(lib.edv_attn_spatial(qkv.data_ptr(), o.data_ptr(), F, N, heads, ws.data_ptr(), nb, st())))
     print(f"attn F={F} N={N} heads={heads}: {t*1e6:8.1f} us  {4*N*N*64*heads*F/t/1e12:6.1f} TF", flush=True)
 
 
@@ -64,6 +66,11 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "sb":
         gemm_sb(M, 384, 1536, res=True, label=f"fc2 T{T}")
     gemm_sb(8192, 8192, 1024, label="8k8k1k")
     gemm_sb(4096, 4096, 4096, label="4096^3")
+elif __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "attn":
+    import os
+    print("EDV_ATTN_PLAIN", os.environ.get("EDV_ATTN_PLAIN"), "EDV_ATTN_KT", os.environ.get("EDV_ATTN_KT"))
+    for F, N, h in ((8, 1370, 6), (32, 1370, 6), (1, 1370, 6), (2, 1370, 6), (4, 1370, 6), (16, 1370, 12), (32, 1370, 16), (8, 4096, 6)):
+        attn(F, N, h)
 elif __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "sweep":
     import os
     print("EDV_GEMM_TILE", os.environ.get("EDV_GEMM_TILE"), "EDV_ATTN_WAVES", os.environ.get("EDV_ATTN_WAVES"))

@@ -225,7 +225,18 @@ def test_conv_transpose(lib, cuda, Fr, h, w, Cc, s):
 
 
 # ----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("Fr,N,heads", [(2, 1370, 6), (1, 64, 2), (3, 10, 1), (1, 129, 12), (2, 321, 6), (1, 1369, 16)])
+def attn_spatial(lib, cuda, qd, o, Fr, N, heads):
+    """edv_attn_spatial with the split workspace the planner asks for (poisoned, so a piece nobody wrote shows)."""
+    nbytes = lib.edv_attn_spatial_workspace(Fr, N, heads)
+    ws = torch.full((max(nbytes // 4, 4),), float("nan"), device=cuda)
+    _lib.check(lib.edv_attn_spatial(qd.data_ptr(), o.data_ptr(), Fr, N, heads, ws.data_ptr(), nbytes, st()), "edv_attn_spatial")
+    return nbytes
+
+
+# (8, 1370, 6) is the bench shape: 528 tasks on 512 resident slots = one whole round + 16 tasks split by keys;
+# (24, 1370, 1) leaves 264 tasks, all split; (40, 300, 16) runs several whole rounds with a long split tail.
+@pytest.mark.parametrize("Fr,N,heads", [(2, 1370, 6), (1, 64, 2), (3, 10, 1), (1, 129, 12), (2, 321, 6), (1, 1369, 16), (8, 1370, 6), (24, 1370, 1),
+                                        (40, 300, 16), (1, 4096, 1)])
 def test_attn_spatial(lib, cuda, Fr, N, heads):
     D = heads * 64
     qkv = rnd(Fr * N, 3 * D, seed=1, scale=2.0)
@@ -234,8 +245,21 @@ def test_attn_spatial(lib, cuda, Fr, N, heads):
     ref = ((q @ k.transpose(-2, -1)).softmax(-1) @ v).transpose(1, 2).reshape(Fr * N, D)
     qd = qkv.to(cuda)
     o = torch.full((Fr * N, D), float("nan"), device=cuda)
-    _lib.check(lib.edv_attn_spatial(qd.data_ptr(), o.data_ptr(), Fr, N, heads, st()), "edv_attn_spatial")
+    attn_spatial(lib, cuda, qd, o, Fr, N, heads)
     close(o, ref, 5e-6, "attn_spatial")
+
+
+def test_attn_spatial_workspace_contract(lib, cuda):
+    """A split plan without (enough) workspace is refused, never run unsplit or out of bounds."""
+    Fr, N, heads = 1, 1370, 6
+    need = lib.edv_attn_spatial_workspace(Fr, N, heads)
+    assert need > 0 and need % 16 == 0
+    qd = torch.zeros(Fr * N, 3 * heads * 64, device=cuda)
+    o = torch.empty(Fr * N, heads * 64, device=cuda)
+    small = torch.empty(need // 4 - 4, device=cuda)
+    assert lib.edv_attn_spatial(qd.data_ptr(), o.data_ptr(), Fr, N, heads, None, 0, st()) != 0
+    assert lib.edv_attn_spatial(qd.data_ptr(), o.data_ptr(), Fr, N, heads, small.data_ptr(), need - 16, st()) != 0
+    assert "workspace" in lib.edv_last_error().decode()
 
 
 def test_attn_spatial_peaked_rows(lib, cuda):
@@ -248,7 +272,7 @@ def test_attn_spatial_peaked_rows(lib, cuda):
     ref = (((t[0] * 0.125) @ t[1].transpose(-2, -1)).softmax(-1) @ t[2]).transpose(1, 2).reshape(Fr * N, D)
     qd = qkv.to(cuda)
     o = torch.empty((Fr * N, D), device=cuda)
-    _lib.check(lib.edv_attn_spatial(qd.data_ptr(), o.data_ptr(), Fr, N, heads, st()))
+    attn_spatial(lib, cuda, qd, o, Fr, N, heads)
     close(o, ref, 5e-6, "attn_spatial peaked")
 
 

@@ -11,11 +11,13 @@ int edv_layernorm(const float *x_dev, const float *w_dev, const float *b_dev, fl
     return layernorm(x_dev, identity_map(), w_dev, b_dev, y_dev, identity_map(), rows, dim, eps, pe_dev, rows_per_frame, T, (hipStream_t)stream);
 }
 
+size_t edv_gemm_workspace(void) { return gemm_workspace() * sizeof(float); }
 int edv_gemm(const float *A_dev, const float *W_dev, float *C_dev, int64_t M, int32_t N, int32_t K, const float *bias_dev, int32_t act,
-             const float *gamma_dev, const float *R_dev, void *stream) {
+             const float *gamma_dev, const float *R_dev, float *workspace_dev, size_t workspace_bytes, void *stream) {
     GemmDesc g;
     g.A = A_dev; g.lda = K; g.W = W_dev; g.ldw = K; g.C = C_dev; g.ldc = N; g.M = M; g.N = N; g.K = K;
     g.bias = bias_dev; g.act = act; g.gamma = gamma_dev; g.R1 = R_dev; g.ldr1 = N;
+    g.ws = workspace_dev; g.ws_floats = workspace_bytes / sizeof(float);
     EDV_CHECK(act >= ACT_NONE && act <= ACT_RELU, "act must be 0, 1 or 2");
     return gemm(g, (hipStream_t)stream);
 }

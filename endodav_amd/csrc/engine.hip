@@ -146,6 +146,13 @@ struct Run {
     int pk(const std::string &name, size_t n, float **out) { return alloc_buf(c, c->packed, name, n, st, out); }
 
     // ---- op wrappers ----------------------------------------------------------------------
+    float *skws = nullptr;  // stream-K split workspace of the stream this Run is enqueueing on
+    size_t skws_floats = 0;
+    int gemm_ws(GemmDesc &g) {
+        g.ws = skws;
+        g.ws_floats = skws_floats;
+        return gemm(g, st);
+    }
     int linear(const float *A, long long M, int K, const float *W, int N, const float *bias, float *C, int act = ACT_NONE,
                const float *gamma = nullptr, const float *R1 = nullptr) {
         GemmDesc g;
@@ -153,7 +160,7 @@ struct Run {
         g.bias = bias; g.act = act; g.gamma = gamma; g.R1 = R1; g.ldr1 = N;
         c->launches++;
         Bracket b_(c, KC_LINEAR, st);
-        return gemm(g, st);
+        return gemm_ws(g);
     }
     int conv3(const float *x, int H, int W, int Cin, const float *wp, const float *bias, int Cout, int stride, float *y, bool pre_relu,
               int act = ACT_NONE, const float *R1 = nullptr, const float *R2 = nullptr) {
@@ -164,7 +171,7 @@ struct Run {
         g.loader = LOAD_CONV3; g.cH = H; g.cW = W; g.cC = Cin; g.cOH = OH; g.cOW = OW; g.cS = stride; g.pre_relu = pre_relu ? 1 : 0;
         c->launches++;
         Bracket b_(c, KC_CONV3, st);
-        return gemm(g, st);
+        return gemm_ws(g);
     }
     int ln(const float *x, RowMap im, const std::string &prefix, float *y, long long rows, int dim, float eps, const float *pe = nullptr,
            int rpf = 0, int TT = 0) {
@@ -445,7 +452,7 @@ struct Run {
             g.A = xt; g.lda = D; g.a_map = RowMap{P0, ntok, c0}; g.W = w; g.ldw = D; g.C = t1; g.ldc = Cb; g.M = MP; g.N = Cb; g.K = D;
             c->launches++;
             Bracket b_(c, KC_LINEAR, st);
-            EDV_TRY(gemm(g, st));
+            EDV_TRY(gemm_ws(g));
         }
         EDV_TRY(param(p + ".norm1.weight", &nw));
         EDV_TRY(param(p + ".norm1.bias", &nb));
@@ -470,6 +477,8 @@ struct Run {
         const float *pos;
         float *attws;      // attention split workspace, one region of attws_each floats per encoder stream
         size_t attws_each;
+        float *skws;       // GEMM stream-K workspace, one region of skws_each floats per encoder stream
+        size_t skws_each;
     };
     int ensure_streams() {
         if (c->sub[0]) return 0;
@@ -483,6 +492,8 @@ struct Run {
     // encoder on frames [f0, f0 + nf) enqueued on stream s (vision_transformer.py:279-289 + :317-321)
     int encoder_range(const EncBufs &eb, const float *x, int f0, int nf, int H, int W, hipStream_t s, int lane = 0) {
         st = s;
+        skws = eb.skws ? eb.skws + (size_t)lane * eb.skws_each : nullptr;
+        skws_floats = eb.skws_each;
         F = nf;
         const long long MT = (long long)nf * ntok;
         float *cols = eb.cols + (size_t)f0 * P0 * 588, *xt = eb.xt + (size_t)f0 * ntok * D, *xn = eb.xn + (size_t)f0 * ntok * D;
@@ -505,7 +516,7 @@ struct Run {
             g.bias = b;
             g.c_map = RowMap{P0, ntok, c0};
             g.R1 = pos; g.ldr1 = D; g.r1_map = RowMap{P0, 0, c0};
-            EDV_TRY(gemm(g, st));
+            EDV_TRY(gemm_ws(g));
             c->launches++;
             if (c0) {
                 const float *cls;
@@ -596,7 +607,20 @@ struct Run {
         }
         float *attws = nullptr;
         if (attws_each) EDV_TRY(wsbuf("attws", attws_each * nstreams, &attws));
-        EncBufs eb{cols, xt, xn, qkv, att, hid, {tap[0], tap[1], tap[2], tap[3]}, {tapcls[0], tapcls[1], tapcls[2], tapcls[3]}, pos, attws, attws_each};
+        // Stream-K for the dense GEMMs is opt-in (EDV_GEMM_STREAMK=1): with 4-5 co-resident 64x64-tile workgroups per CU
+        // the statically assigned persistent form measured SLOWER than the plain grid (qkv T=8 122 vs 109 us) because
+        // the SIMD issues oldest-wave-first and the young workgroups of a CU starve (profiles/r01_gemm_tile_sweep.txt).
+        static const bool gemm_streamk = [] {
+            const char *e = getenv("EDV_GEMM_STREAMK");
+            return e && atoi(e) != 0;
+        }();
+        const size_t skws_each = gemm_streamk ? gemm_workspace() : 0;
+        float *skws_all = nullptr;
+        if (skws_each) EDV_TRY(wsbuf("skws", skws_each * nstreams, &skws_all));
+        EncBufs eb{cols, xt, xn, qkv, att, hid, {tap[0], tap[1], tap[2], tap[3]}, {tapcls[0], tapcls[1], tapcls[2], tapcls[3]}, pos, attws, attws_each,
+                   skws_all, skws_each};
+        skws = skws_all;  // the head runs on the caller's stream with region 0 (the encoder streams have joined by then)
+        skws_floats = skws_each;
         if (nstreams == 1) {
             EDV_TRY(encoder_range(eb, x, 0, F, H, W, st));
         } else {
@@ -609,7 +633,7 @@ struct Run {
                 const int nf = (Fall - f0) / (nstreams - h);  // even split of the remaining frames
                 EDV_HIP(hipStreamWaitEvent(c->sub[h], c->ev_fork, 0));
                 const int rc = encoder_range(eb, x, f0, nf, H, W, c->sub[h], h);
-                st = user; F = Fall;
+                st = user; F = Fall; skws = skws_all;
                 if (rc) return rc;
                 EDV_HIP(hipEventRecord(c->ev_join[h], c->sub[h]));
                 EDV_HIP(hipStreamWaitEvent(user, c->ev_join[h], 0));
@@ -649,12 +673,12 @@ struct Run {
                 EDV_TRY(param(rp + ".bias", &rbias));
                 GemmDesc g1;
                 g1.A = tapcls[j]; g1.lda = D; g1.W = rw + D; g1.ldw = 2 * D; g1.C = fbias; g1.ldc = D; g1.M = F; g1.N = D; g1.K = D; g1.bias = rbias;
-                EDV_TRY(gemm(g1, st));
+                EDV_TRY(gemm_ws(g1));
                 GemmDesc g2;
                 g2.A = tap[j]; g2.lda = D; g2.W = rw; g2.ldw = 2 * D; g2.C = readout; g2.ldc = D; g2.M = MP; g2.N = D; g2.K = D;
                 g2.P1 = fbias; g2.ldp1 = D; g2.act = ACT_GELU;
                 g2.p1_map = RowMap{P0, 1, 0, 0};  // inner 0: one bias row per frame
-                EDV_TRY(gemm(g2, st));
+                EDV_TRY(gemm_ws(g2));
                 c->launches += 2;
                 src = readout;
                 c->stages["tapcls" + std::to_string(j)] = {tapcls[j], (size_t)F * D};
@@ -674,7 +698,7 @@ struct Run {
                 GemmDesc g;
                 g.A = pj; g.lda = oc[j]; g.W = wt; g.ldw = oc[j]; g.C = j == 0 ? l1 : l2; g.M = MP; g.N = s * s * oc[j]; g.K = oc[j];
                 g.bias = bt; g.store = STORE_SHUFFLE; g.ps_s = s; g.ps_C = oc[j]; g.ps_h = ph; g.ps_w = pw; g.ldc = oc[j];
-                EDV_TRY(gemm(g, st));
+                EDV_TRY(gemm_ws(g));
                 c->launches++;
             } else if (j == 3) {
                 const float *wc, *bc;

@@ -65,6 +65,29 @@ __device__ __forceinline__ void gemm_epilogue(const GemmDesc &g, f32x16 (&acc)[F
 }
 
 
+// The same epilogue for ONE element (used by the stream-K fix-up kernel, which sums the pieces of a split tile).
+template <int STORE>
+__device__ __forceinline__ void gemm_epilogue_elem(const GemmDesc &g, float accv, long long m, int n) {
+    float pre = accv + (g.bias ? g.bias[n] : 0.f);
+    if (g.P1) pre += g.P1[g.p1_map(m) * g.ldp1 + n];
+    float v = apply_act(pre, g.act) * (g.gamma ? g.gamma[n] : 1.f);
+    if (STORE == STORE_ROWS) {
+        const long long crow = g.c_map(m);
+        if (g.R1) v += g.R1[g.r1_map(m) * g.ldr1 + n];
+        if (g.R2) v += g.R2[crow * g.ldr2 + n];
+        g.C[crow * g.ldc + n] = v;
+    } else {
+        const int ps_sub = n / g.ps_C, ps_co = n - ps_sub * g.ps_C;
+        const int ps_dy = ps_sub / g.ps_s, ps_dx = ps_sub - ps_dy * g.ps_s;
+        const int gp = g.ps_h * g.ps_w;
+        const long long f = m / gp;
+        const int p = (int)(m - f * gp);
+        const int y = p / g.ps_w, x = p - y * g.ps_w;
+        const long long orow = (f * g.ps_h * g.ps_s + (long long)y * g.ps_s + ps_dy) * (g.ps_w * g.ps_s) + x * g.ps_s + ps_dx;
+        g.C[orow * g.ps_C + ps_co] = v;
+    }
+}
+
 // ---- compact epilogue for the common case -----------------------------------------------------------------------------
 // The general epilogue above unrolls 16 rows x every optional feature (row maps with 64-bit divisions, P1, a runtime
 // activation switch with an inlined erff per row): ~11 000 instructions, more than the 64 KB instruction cache two CUs

@@ -8,6 +8,9 @@ sys.path.insert(0, ".")
 from endodav_amd import _lib
 
 lib = _lib.load()
+import os as _os
+import torch as _t
+GWS = _t.empty(lib.edv_gemm_workspace() // 4 if not _os.environ.get('KB_NO_WS') else 4, device='cuda:0')
 dev = torch.device("cuda:0")
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -31,7 +34,7 @@ def gemm(M, N, K, act=0, res=False, label=""):
     Cm = torch.empty(M, N, device=dev)
     b = torch.randn(N, device=dev)
     R = torch.randn(M, N, device=dev) if res else None
-    t = timeit(lambda: _lib.check(lib.edv_gemm(A.data_ptr(), W.data_ptr(), Cm.data_ptr(), M, N, K, b.data_ptr(), act, None, _lib.ptr(R), st())))
+    t = timeit(lambda: _lib.check(lib.edv_gemm(A.data_ptr(), W.data_ptr(), Cm.data_ptr(), M, N, K, b.data_ptr(), act, None, _lib.ptr(R), (GWS.data_ptr() if GWS.numel() > 4 else None), (GWS.numel() * 4 if GWS.numel() > 4 else 0), st())))
     print(f"gemm {label:10s} M={M:6d} N={N:5d} K={K:5d} act={act} res={int(res)}: {t*1e6:8.1f} us  {2*M*N*K/t/1e12:6.1f} TF", flush=True)
 
 

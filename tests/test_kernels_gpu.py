@@ -52,6 +52,18 @@ def test_layernorm_with_temporal_pe(lib, cuda):
 
 
 # ----------------------------------------------------------------------------------------------
+_WS = {}
+
+
+def gemm_ws(lib, cuda):
+    """The stream-K workspace edv_gemm_workspace() asks for, poisoned once (pieces nobody wrote would show as NaN)."""
+    if "ws" not in _WS:
+        nbytes = lib.edv_gemm_workspace()
+        assert nbytes > 0 and nbytes % 16 == 0
+        _WS["ws"] = (torch.full((nbytes // 4,), float("nan"), device=cuda), nbytes)
+    return _WS["ws"]
+
+
 @pytest.mark.parametrize("M,N,K,act,use_bias,use_gamma,use_res", [
     (300, 384, 384, 0, True, False, False),
     (2 * 1370, 1152, 384, 0, True, False, False),     # qkv
@@ -64,8 +76,12 @@ def test_layernorm_with_temporal_pe(lib, cuda):
     (999, 16, 64, 0, False, False, False),            # N < 32
     (3, 96, 96, 0, True, False, False),               # tiny M
     (5000, 768, 48, 0, True, False, False),           # ConvT-like
+    (8 * 1370, 384, 384, 0, True, True, True),        # proj at T=8: 1032 tiles, one round + 8 tiles split along K
+    (8 * 1370, 384, 1536, 0, True, True, True),       # fc2 at T=8: 48 k-tiles per split tile
+    (700 * 64, 64, 64, 2, True, False, True),         # 2 k-tiles per tile: pieces of a single k-tile
 ])
-def test_gemm(lib, cuda, M, N, K, act, use_bias, use_gamma, use_res):
+@pytest.mark.parametrize("split", [False, True], ids=["plain", "streamk"])
+def test_gemm(lib, cuda, M, N, K, act, use_bias, use_gamma, use_res, split):
     A, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K))
     bias = rnd(N, seed=3, scale=0.1) if use_bias else None
     gamma = rnd(N, seed=4) + 1.2 if use_gamma else None
@@ -84,7 +100,9 @@ def test_gemm(lib, cuda, M, N, K, act, use_bias, use_gamma, use_res):
     d = lambda t: None if t is None else t.to(cuda)
     Ad, Wd, bd, gd, Rd = d(A), d(W), d(bias), d(gamma), d(R)
     Cd = torch.full((M, N), float("nan"), device=cuda)
-    _lib.check(lib.edv_gemm(Ad.data_ptr(), Wd.data_ptr(), Cd.data_ptr(), M, N, K, _lib.ptr(bd), act, _lib.ptr(gd), _lib.ptr(Rd), st()), "edv_gemm")
+    ws, nbytes = gemm_ws(lib, cuda) if split else (None, 0)
+    _lib.check(lib.edv_gemm(Ad.data_ptr(), Wd.data_ptr(), Cd.data_ptr(), M, N, K, _lib.ptr(bd), act, _lib.ptr(gd), _lib.ptr(Rd), _lib.ptr(ws), nbytes, st()),
+               "edv_gemm")
     close(Cd, ref, 3e-6, f"gemm {M}x{N}x{K}")
 
 
@@ -123,7 +141,7 @@ def test_gemm_split_bf16(lib, cuda, M, N, K, act, use_bias, use_gamma, use_res):
                "edv_gemm_sb")
     e_sb = close(Cd, ref, 3e-6, f"gemm_sb {M}x{N}x{K}")
     Cf = torch.empty((M, N), device=cuda)
-    _lib.check(lib.edv_gemm(Ad.data_ptr(), Wd.data_ptr(), Cf.data_ptr(), M, N, K, _lib.ptr(bd), act, _lib.ptr(gd), _lib.ptr(Rd), st()))
+    _lib.check(lib.edv_gemm(Ad.data_ptr(), Wd.data_ptr(), Cf.data_ptr(), M, N, K, _lib.ptr(bd), act, _lib.ptr(gd), _lib.ptr(Rd), None, 0, st()))
     e_f32 = close(Cf, ref, 3e-6, "gemm f32")
     print(f"\n[{M}x{N}x{K}] error vs fp64: split-bf16 {e_sb:.2e}, fp32 MFMA {e_f32:.2e}")
     # the three planes reassemble W exactly
@@ -131,19 +149,21 @@ def test_gemm_split_bf16(lib, cuda, M, N, K, act, use_bias, use_gamma, use_res):
     assert torch.equal(p, Wd)
 
 
-def test_gemm_inplace_residual(lib, cuda):
+@pytest.mark.parametrize("M,split", [(1370, False), (8 * 1370, True)], ids=["plain", "streamk"])
+def test_gemm_inplace_residual(lib, cuda, M, split):
     """proj / fc2 write the residual stream in place (C aliases R)."""
-    M, N, K = 1370, 384, 384
+    N, K = 384, 384
+    ws, nbytes = gemm_ws(lib, cuda) if split else (None, 0)
     A, W, X = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=0.05), rnd(M, N, seed=3)
     ref = X.double() + A.double() @ W.double().T
     Ad, Wd, Xd = A.to(cuda), W.to(cuda), X.to(cuda)
-    _lib.check(lib.edv_gemm(Ad.data_ptr(), Wd.data_ptr(), Xd.data_ptr(), M, N, K, None, 0, None, Xd.data_ptr(), st()))
+    _lib.check(lib.edv_gemm(Ad.data_ptr(), Wd.data_ptr(), Xd.data_ptr(), M, N, K, None, 0, None, Xd.data_ptr(), _lib.ptr(ws), nbytes, st()))
     close(Xd, ref, 3e-6, "in-place residual")
 
 
 def test_gemm_rejects_bad_k(lib, cuda):
     a = torch.zeros(8, 6, device=cuda)
-    assert lib.edv_gemm(a.data_ptr(), a.data_ptr(), a.data_ptr(), 8, 8, 6, None, 0, None, None, st()) != 0
+    assert lib.edv_gemm(a.data_ptr(), a.data_ptr(), a.data_ptr(), 8, 8, 6, None, 0, None, None, None, 0, st()) != 0
     assert b"multiple of 4" in lib.edv_last_error()
 
 

@@ -73,7 +73,21 @@ SIGNATURES = {
     "edv_pack_conv3x3": (C.c_int, [_fp, _fp, _i32, _i32, C.c_void_p]),
     "edv_conv_transpose": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
     "edv_attn_spatial_workspace": (C.c_size_t, [_i32, _i32, _i32]),
-    "edv_attn_spatial": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _fp, C.c_size_t, C.c_void_p]),
+    "edv_attn_spatial": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _fp, C.c_size_t, _fp, C.c_void_p]),
+    "edv_attn_spatial_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, C.c_void_p]),
+    "edv_layernorm_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _i64, _i32, C.c_float, _i32, C.c_void_p]),
+    "edv_ew_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _i64, _i32, C.c_void_p]),
+    "edv_geglu_bwd": (C.c_int, [_fp, _fp, _fp, _i64, _i32, C.c_void_p]),
+    "edv_transpose_scale": (C.c_int, [_fp, _fp, _fp, _i32, _i32, C.c_void_p]),
+    "edv_lora_grads_workspace": (C.c_size_t, [_i64, _i32, _i32, _i32]),
+    "edv_lora_grads": (C.c_int, [_fp, _fp, _i64, _i32, _i32, _i32, _fp, _fp, _fp, _fp, C.c_float, _fp, _fp, C.c_size_t, _fp, _fp, _fp, _fp, C.c_void_p]),
+    "edv_bilinear_bwd": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
+    "edv_dot_channels_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i64, _i32, C.c_void_p]),
+    "edv_groupnorm_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
+    "edv_attn_temporal_bwd": (C.c_int, [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
+    "edv_pack_conv3x3_bwd": (C.c_int, [_fp, _fp, _i32, _i32, C.c_void_p]),
+    "edv_conv3x3_s2_bwd": (C.c_int, [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
+    "edv_pixel_unshuffle": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
     "edv_attn_temporal": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
     "edv_groupnorm": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _f32, C.c_void_p]),
     "edv_geglu": (C.c_int, [_fp, _fp, _i64, _i32, C.c_void_p]),

@@ -77,8 +77,59 @@ int edv_conv_transpose(const float *x_dev, const float *w_dev, const float *b_de
 
 size_t edv_attn_spatial_workspace(int32_t F, int32_t N, int32_t heads) { return attn_spatial_workspace(F, N, heads) * sizeof(float); }
 int edv_attn_spatial(const float *qkv_dev, float *out_dev, int32_t F, int32_t N, int32_t heads, float *workspace_dev, size_t workspace_bytes,
+                     float *lse_dev, void *stream) {
+    return attn_spatial(qkv_dev, out_dev, F, N, heads, workspace_dev, workspace_bytes / sizeof(float), (hipStream_t)stream, lse_dev);
+}
+int edv_attn_spatial_bwd(const float *qkv_dev, const float *out_dev, const float *dout_dev, const float *lse_dev, float *delta_dev, float *dqkv_dev,
+                         int32_t F, int32_t N, int32_t heads, void *stream) {
+    return attn_spatial_bwd(qkv_dev, out_dev, dout_dev, lse_dev, delta_dev, dqkv_dev, F, N, heads, (hipStream_t)stream);
+}
+int edv_layernorm_bwd(const float *x_dev, const float *w_dev, const float *dy_dev, float *dx_dev, int64_t rows, int32_t dim, float eps, int32_t accumulate,
+                      void *stream) {
+    return layernorm_bwd(x_dev, identity_map(), w_dev, dy_dev, identity_map(), dx_dev, identity_map(), rows, dim, eps, accumulate != 0, (hipStream_t)stream);
+}
+int edv_ew_bwd(const float *d_dev, const float *src_dev, const float *add_dev, float *out_dev, int64_t n, int32_t mode, void *stream) {
+    return ew_bwd(d_dev, src_dev, add_dev, out_dev, n, mode, (hipStream_t)stream);
+}
+int edv_geglu_bwd(const float *x_dev, const float *dy_dev, float *dx_dev, int64_t M, int32_t inner, void *stream) {
+    return geglu_bwd(x_dev, dy_dev, dx_dev, M, inner, (hipStream_t)stream);
+}
+int edv_transpose_scale(const float *W_dev, const float *gamma_dev, float *Wt_dev, int32_t N, int32_t K, void *stream) {
+    return transpose_scale(W_dev, K, gamma_dev, Wt_dev, N, K, (hipStream_t)stream);
+}
+size_t edv_lora_grads_workspace(int64_t M, int32_t nin, int32_t nout, int32_t r) { return lora_grads_workspace(M, nin, nout, r) * sizeof(float); }
+int edv_lora_grads(const float *x_dev, const float *g_dev, int64_t M, int32_t nin, int32_t nout, int32_t r, const float *A_dev, const float *B_dev,
+                   const float *U_dev, const float *V_dev, float s, const float *gamma_dev, float *workspace_dev, size_t workspace_bytes, float *dA_dev,
+                   float *dB_dev, float *dU_dev, float *dV_dev, void *stream) {
+    EDV_CHECK(M > 0 && nin > 0 && nout > 0 && nin % 4 == 0 && nout % 4 == 0, "shape");
+    return lora_grads(x_dev, nin, g_dev, nout, M, nin, nout, r, A_dev, B_dev, U_dev, V_dev, s, gamma_dev, workspace_dev, workspace_bytes / sizeof(float),
+                      dA_dev, dB_dev, dU_dev, dV_dev, (hipStream_t)stream);
+}
+int edv_bilinear_bwd(const float *dy_dev, float *dx_dev, int32_t F, int32_t ih, int32_t iw, int32_t C, int32_t oh, int32_t ow, int32_t accumulate,
                      void *stream) {
-    return attn_spatial(qkv_dev, out_dev, F, N, heads, workspace_dev, workspace_bytes / sizeof(float), (hipStream_t)stream);
+    return bilinear_bwd(dy_dev, dx_dev, F, ih, iw, C, oh, ow, accumulate != 0, (hipStream_t)stream);
+}
+int edv_dot_channels_bwd(const float *g_dev, const float *disp_dev, const float *w_dev, const float *o2_dev, float *d_o2_dev, int64_t npix, int32_t C,
+                         void *stream) {
+    return dot_channels_bwd(g_dev, disp_dev, w_dev, o2_dev, d_o2_dev, npix, C, (hipStream_t)stream);
+}
+int edv_groupnorm_bwd(const float *x_dev, const float *stats_dev, const float *w_dev, const float *dy_dev, float *sums_dev, float *dx_dev, int32_t F,
+                      int32_t P, int32_t C, int32_t groups, int32_t accumulate, void *stream) {
+    return groupnorm_bwd(x_dev, stats_dev, w_dev, dy_dev, sums_dev, dx_dev, F, P, C, groups, accumulate != 0, (hipStream_t)stream);
+}
+int edv_attn_temporal_bwd(const float *qkv_dev, const float *dout_dev, float *dqkv_dev, int32_t B, int32_t T, int32_t P, int32_t C, int32_t heads,
+                          void *stream) {
+    return attn_temporal_bwd(qkv_dev, dout_dev, dqkv_dev, B, T, P, C, heads, (hipStream_t)stream);
+}
+int edv_pack_conv3x3_bwd(const float *w_dev, float *wpacked_dev, int32_t Cout, int32_t Cin, void *stream) {
+    return pack_conv3x3_bwd(w_dev, wpacked_dev, Cout, Cin, (hipStream_t)stream);
+}
+int edv_conv3x3_s2_bwd(const float *dy_dev, const float *wpacked_dev, float *dx_dev, int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                       void *stream) {
+    return conv3x3_s2_bwd(dy_dev, wpacked_dev, dx_dev, F, H, W, Cin, Cout, (hipStream_t)stream);
+}
+int edv_pixel_unshuffle(const float *dy_dev, float *A_dev, int32_t F, int32_t h, int32_t w, int32_t C, int32_t s, void *stream) {
+    return pixel_unshuffle(dy_dev, A_dev, F, h, w, C, s, (hipStream_t)stream);
 }
 
 int edv_attn_temporal(const float *qkv_dev, float *out_dev, int32_t B, int32_t T, int32_t P, int32_t C, int32_t heads, void *stream) {

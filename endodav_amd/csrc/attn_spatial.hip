@@ -47,7 +47,7 @@ constexpr int KS = HD + 4;   // padded K row stride: 68r mod 64 = 4r -> conflict
 // 3 instead of 2 waves per SIMD) but measured no faster, so 64 stays the default; EDV_ATTN_KT=32 selects the other.
 template <int NW, int KT>
 __global__ __launch_bounds__(NW * 64) void attn_spatial_kernel(const float *__restrict__ qkv, float *__restrict__ out, float *__restrict__ ws,
-                                                               int N, int heads, int whole_rounds, long long units, int chunk) {
+                                                               float *__restrict__ lse, int N, int heads, int whole_rounds, long long units, int chunk) {
     constexpr int QB = NW * 32;
     constexpr int NT = NW * 64;
     constexpr int SLOTF = QB * (HD + 2);  // workspace slot: O [QB][64], m [QB], l [QB]
@@ -221,6 +221,8 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_kernel(const float *__re
             }
         } else if (qi < N) {
             orow = out + ((long long)frame * N + qi) * D + head * HD;
+            // training: per-row log-sum-exp in base 2, read by attn_spatial_bwd.hip
+            if (lse && lh == 0) lse[((long long)frame * heads + head) * N + qi] = m_run + log2f(l_tot);
         }
         if (orow) {
 #pragma unroll
@@ -238,8 +240,8 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_kernel(const float *__re
 // Merge of the pieces of every split (leftover) task.  Piece list of leftover task t: the workgroups whose unit runs
 // [g*chunk, (g+1)*chunk) intersect [t*ntiles, (t+1)*ntiles); a workgroup's piece sits in its slot 0 when its first unit
 // lies in this task, else in slot 1.  Thread = (query, 16-byte output chunk); 16 queries per 256-thread block.
-__global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restrict__ ws, float *__restrict__ out, int N, int heads, int QB, int ntiles,
-                                                           int task_l0, long long units, int chunk) {
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restrict__ ws, float *__restrict__ out, float *__restrict__ lse, int N, int heads,
+                                                           int QB, int ntiles, int task_l0, long long units, int chunk) {
     const int t = blockIdx.x;
     const int ql = blockIdx.y * 16 + (threadIdx.x >> 4), ch = threadIdx.x & 15;
     const long long ub = (long long)t * ntiles, ue = ub + ntiles;
@@ -283,6 +285,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restri
     }
     const float inv = 1.0f / lsum;
     *reinterpret_cast<f32x4 *>(out + ((long long)frame * N + qi) * (heads * HD) + head * HD + ch * 4) = acc * inv;
+    if (lse && ch == 0) lse[((long long)frame * heads + head) * N + qi] = M + log2f(lsum);
 }
 
 struct AttnPlan {
@@ -351,7 +354,7 @@ size_t attn_spatial_workspace(int F, int N, int heads) {
     return p.ws_floats;
 }
 
-int attn_spatial(const float *qkv, float *out, int F, int N, int heads, float *ws, size_t ws_floats, hipStream_t st) {
+int attn_spatial(const float *qkv, float *out, int F, int N, int heads, float *ws, size_t ws_floats, hipStream_t st, float *lse) {
     EDV_CHECK(qkv && out, "null operand");
     EDV_CHECK(F > 0 && N > 0 && heads > 0, "empty problem");
     EDV_CHECK(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 16 == 0), "16-byte alignment");
@@ -360,17 +363,17 @@ int attn_spatial(const float *qkv, float *out, int F, int N, int heads, float *w
     EDV_CHECK(p.ws_floats == 0 || (ws && ws_floats >= p.ws_floats && (uintptr_t)ws % 16 == 0), "attention workspace too small (attn_spatial_workspace)");
     dim3 grid((unsigned)p.grid);
     if (p.nw == 4 && p.kt == 32)
-        hipLaunchKernelGGL((attn_spatial_kernel<4, 32>), grid, dim3(256), 0, st, qkv, out, ws, N, heads, p.whole_rounds, p.units, p.chunk);
+        hipLaunchKernelGGL((attn_spatial_kernel<4, 32>), grid, dim3(256), 0, st, qkv, out, ws, lse, N, heads, p.whole_rounds, p.units, p.chunk);
     else if (p.nw == 4)
-        hipLaunchKernelGGL((attn_spatial_kernel<4, 64>), grid, dim3(256), 0, st, qkv, out, ws, N, heads, p.whole_rounds, p.units, p.chunk);
+        hipLaunchKernelGGL((attn_spatial_kernel<4, 64>), grid, dim3(256), 0, st, qkv, out, ws, lse, N, heads, p.whole_rounds, p.units, p.chunk);
     else if (p.nw == 2)
-        hipLaunchKernelGGL((attn_spatial_kernel<2, 32>), grid, dim3(128), 0, st, qkv, out, ws, N, heads, p.whole_rounds, p.units, p.chunk);
+        hipLaunchKernelGGL((attn_spatial_kernel<2, 32>), grid, dim3(128), 0, st, qkv, out, ws, lse, N, heads, p.whole_rounds, p.units, p.chunk);
     else
-        hipLaunchKernelGGL((attn_spatial_kernel<1, 32>), grid, dim3(64), 0, st, qkv, out, ws, N, heads, p.whole_rounds, p.units, p.chunk);
+        hipLaunchKernelGGL((attn_spatial_kernel<1, 32>), grid, dim3(64), 0, st, qkv, out, ws, lse, N, heads, p.whole_rounds, p.units, p.chunk);
     EDV_LAUNCH_OK();
     if (p.leftover) {
         const int QB = p.nw * 32;
-        hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)p.leftover, (unsigned)(QB / 16)), dim3(256), 0, st, ws, out, N, heads, QB, p.ntiles,
+        hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)p.leftover, (unsigned)(QB / 16)), dim3(256), 0, st, ws, out, lse, N, heads, QB, p.ntiles,
                            p.whole_rounds * p.grid, p.units, p.chunk);
         EDV_LAUNCH_OK();
     }

@@ -1,0 +1,228 @@
+// Encoder self-attention, backward (flash-style: no N x N matrix in HBM).  Differentiates attn_spatial.hip /
+// models/backbones/layers/attention.py:60-66:  O = softmax(S) V,  S = (Q d^-1/2) K^T.
+//
+// With the forward's per-row log-sum-exp L (base 2) and delta_q = sum_d dO[q,d] O[q,d]:
+//     P  = exp2(S log2e - L)          dV = P^T dO          dP = dO V^T
+//     dS = P * (dP - delta)           dQ = d^-1/2 dS K     dK = d^-1/2 dS^T Q
+// Two launches of ONE kernel template, both in the forward's transposed MFMA orientation (resident rows on the lanes,
+// streamed 32-row tiles through LDS, v_mfma_f32_32x32x2_f32, permuted-k fragments):
+//   MODE_DQ : resident = 128 queries (Q, dO fragments in registers), streamed = key tiles (K, V)  -> dQ
+//   MODE_DKV: resident = 128 keys    (K, V  fragments in registers), streamed = query tiles (Q, dO) -> dK, dV
+// In both, X1^T = T1 R1^T (scores) and X2^T = T2 R2^T (dP) land as accumulators whose registers are exactly the B
+// operand of the third product (rows of the streamed tile contract), as in the forward's P V step.
+#include <cmath>
+
+#include "ops.hpp"
+
+namespace edv {
+namespace {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int HD = 64;
+constexpr int TS = HD + 4;  // padded row stride of the streamed tiles: conflict-free b128 row reads and b32 column reads
+constexpr int TR = 32;      // rows per streamed tile
+enum { MODE_DQ = 0, MODE_DKV = 1 };
+
+// delta[f, h, q] = sum_d dO[(f,q), h*64+d] * O[(f,q), h*64+d]: 16 lanes per (row, head)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const float *__restrict__ dO, const float *__restrict__ O, float *__restrict__ delta, int F, int N,
+                                                         int heads) {
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long pair = gid >> 4;  // (row, head)
+    const int sub = (int)(gid & 15);
+    const long long total = (long long)F * N * heads;
+    const long long pc = pair < total ? pair : total - 1;
+    const long long row = pc / heads;
+    const int head = (int)(pc - row * heads);
+    const long long off = row * (long long)heads * HD + head * HD + sub * 4;
+    const f32x4 a = *reinterpret_cast<const f32x4 *>(dO + off), b = *reinterpret_cast<const f32x4 *>(O + off);
+    float s = (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (sub == 0 && pair < total) {
+        const long long f = row / N;
+        const int q = (int)(row - f * N);
+        delta[(f * heads + head) * N + q] = s;
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void attn_spatial_bwd_kernel(const float *__restrict__ qkv, const float *__restrict__ dO, const float *__restrict__ lse,
+                                                               const float *__restrict__ delta, float *__restrict__ dqkv, int N, int heads) {
+    __shared__ __attribute__((aligned(16))) float sT1[TR * TS];
+    __shared__ __attribute__((aligned(16))) float sT2[TR * TS];
+    __shared__ __attribute__((aligned(16))) float sL[TR];  // MODE_DKV: lse / delta of the streamed queries
+    __shared__ __attribute__((aligned(16))) float sD[TR];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int nb = (N + 127) / 128;
+    const int blk = blockIdx.x % nb, fh = blockIdx.x / nb;
+    const int head = fh % heads, frame = fh / heads;
+    const int D = heads * HD, D3 = 3 * D;
+    const float *base = qkv + (long long)frame * N * D3 + head * HD;    // q columns; k at +D, v at +2D
+    const float *dobase = dO + (long long)frame * N * D + head * HD;
+    const float *lrow = lse + ((long long)frame * heads + head) * N;
+    const float *drow = delta + ((long long)frame * heads + head) * N;
+
+    const int ri = blk * 128 + wave * 32 + l31;  // resident row of this lane (query in MODE_DQ, key in MODE_DKV)
+    const int rrow = ri < N ? ri : N - 1;
+    const float c1 = 0.125f * 1.44269504088896340736f;  // d^-1/2 * log2(e)
+
+    // resident fragments in permuted-k order: element e of f[qq] is d = 8*qq + 4*lh + e
+    f32x4 r1f[8], r2f[8];
+    {
+        const float *p1 = base + (long long)rrow * D3 + (MODE == MODE_DQ ? 0 : D);
+        const float *p2 = MODE == MODE_DQ ? dobase + (long long)rrow * D : base + (long long)rrow * D3 + 2 * D;
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) {
+            r1f[qq] = *reinterpret_cast<const f32x4 *>(p1 + 8 * qq + 4 * lh) * c1;
+            r2f[qq] = *reinterpret_cast<const f32x4 *>(p2 + 8 * qq + 4 * lh);
+        }
+    }
+    float Lq = 0.f, Dq = 0.f;
+    if (MODE == MODE_DQ) {
+        Lq = lrow[rrow];
+        Dq = drow[rrow];
+    }
+
+    f32x16 o0, o1, o2, o3;  // MODE_DQ: dQ^T (o0, o1);  MODE_DKV: dK^T (o0, o1), dV^T (o2, o3)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o0[r] = o1[r] = o2[r] = o3[r] = 0.f;
+
+    // staging: 32 rows x 16 float4 per array = 512 float4 per array; 256 threads -> 2 per array
+    const int sc = tid & 15, sr = tid >> 4;  // chunk, row (0..15); second pass rows +16
+    f32x4 pa[2], pb[2];
+    float pl = 0.f, pd = 0.f;
+    auto load_tile = [&](int t0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            int tr = t0 + sr + 16 * i;
+            tr = tr < N ? tr : N - 1;  // clamped rows are masked below
+            if (MODE == MODE_DQ) {
+                const float *p = base + (long long)tr * D3 + sc * 4;
+                pa[i] = *reinterpret_cast<const f32x4 *>(p + D);      // K
+                pb[i] = *reinterpret_cast<const f32x4 *>(p + 2 * D);  // V
+            } else {
+                pa[i] = *reinterpret_cast<const f32x4 *>(base + (long long)tr * D3 + sc * 4);  // Q
+                pb[i] = *reinterpret_cast<const f32x4 *>(dobase + (long long)tr * D + sc * 4);  // dO
+            }
+        }
+        if (MODE == MODE_DKV && tid < TR) {
+            int tr = t0 + tid;
+            tr = tr < N ? tr : N - 1;
+            pl = lrow[tr];
+            pd = drow[tr];
+        }
+    };
+
+    const int ntiles = (N + TR - 1) / TR;
+    load_tile(0);
+    for (int t = 0; t < ntiles; ++t) {
+        const int t0 = t * TR;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<f32x4 *>(&sT1[(sr + 16 * i) * TS + sc * 4]) = pa[i];
+            *reinterpret_cast<f32x4 *>(&sT2[(sr + 16 * i) * TS + sc * 4]) = pb[i];
+        }
+        if (MODE == MODE_DKV && tid < TR) {
+            sL[tid] = pl;
+            sD[tid] = pd;
+        }
+        __syncthreads();
+        if (t + 1 < ntiles) load_tile(t0 + TR);
+
+        // ---- X1^T = T1 R1^T (scores, base-2 logits), X2^T = T2 R2^T (dP)
+        f32x16 x1, x2;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) x1[r] = x2[r] = 0.f;
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) {
+            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(&sT1[l31 * TS + 8 * qq + 4 * lh]);
+            const f32x4 a2 = *reinterpret_cast<const f32x4 *>(&sT2[l31 * TS + 8 * qq + 4 * lh]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                x1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], r1f[qq][e], x1, 0, 0, 0);
+                x2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[e], r2f[qq][e], x2, 0, 0, 0);
+            }
+        }
+        // ---- P = exp2(X1 - L), dS = P (dP - delta); register r of lane-half h is streamed row (r&3) + 8*(r>>2) + 4*h
+        if (MODE == MODE_DQ) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int trow = t0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float p = trow < N ? __builtin_amdgcn_exp2f(x1[r] - Lq) : 0.f;
+                x2[r] = p * (x2[r] - Dq);  // dS
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 L4 = *reinterpret_cast<const f32x4 *>(&sL[8 * g + 4 * lh]);
+                const f32x4 D4 = *reinterpret_cast<const f32x4 *>(&sD[8 * g + 4 * lh]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    const int trow = t0 + 8 * g + 4 * lh + e;
+                    const float p = trow < N ? __builtin_amdgcn_exp2f(x1[r] - L4[e]) : 0.f;
+                    x1[r] = p;                    // P
+                    x2[r] = p * (x2[r] - D4[e]);  // dS
+                }
+            }
+        }
+        // ---- third products: streamed rows contract; step r uses rows {row(r,0), row(r,1)} in its two k-slots
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int trl = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float a0 = sT1[trl * TS + l31], a1 = sT1[trl * TS + 32 + l31];
+            o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, x2[r], o0, 0, 0, 0);  // dQ^T += K^T dS^T   |  dK^T += Q^T dS
+            o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, x2[r], o1, 0, 0, 0);
+            if (MODE == MODE_DKV) {
+                const float b0 = sT2[trl * TS + l31], b1 = sT2[trl * TS + 32 + l31];
+                o2 = __builtin_amdgcn_mfma_f32_32x32x2f32(b0, x1[r], o2, 0, 0, 0);  // dV^T += dO^T P
+                o3 = __builtin_amdgcn_mfma_f32_32x32x2f32(b1, x1[r], o3, 0, 0, 0);
+            }
+        }
+    }
+
+    if (ri < N) {
+        float *orow = dqkv + ((long long)frame * N + ri) * D3 + head * HD + (MODE == MODE_DQ ? 0 : D);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 are d = 8g + 4*lh + {0..3}
+            const f32x4 a = {o0[4 * g], o0[4 * g + 1], o0[4 * g + 2], o0[4 * g + 3]};
+            const f32x4 b = {o1[4 * g], o1[4 * g + 1], o1[4 * g + 2], o1[4 * g + 3]};
+            *reinterpret_cast<f32x4 *>(orow + 8 * g + 4 * lh) = a * 0.125f;
+            *reinterpret_cast<f32x4 *>(orow + 32 + 8 * g + 4 * lh) = b * 0.125f;
+            if (MODE == MODE_DKV) {
+                const f32x4 c = {o2[4 * g], o2[4 * g + 1], o2[4 * g + 2], o2[4 * g + 3]};
+                const f32x4 d = {o3[4 * g], o3[4 * g + 1], o3[4 * g + 2], o3[4 * g + 3]};
+                *reinterpret_cast<f32x4 *>(orow + D + 8 * g + 4 * lh) = c;
+                *reinterpret_cast<f32x4 *>(orow + D + 32 + 8 * g + 4 * lh) = d;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// qkv [F*N, 3*heads*64], out/dout [F*N, heads*64], lse/delta [F, heads, N] (delta is scratch written here), dqkv like qkv
+int attn_spatial_bwd(const float *qkv, const float *out, const float *dout, const float *lse, float *delta, float *dqkv, int F, int N, int heads,
+                     hipStream_t st) {
+    EDV_CHECK(qkv && out && dout && lse && delta && dqkv, "null operand");
+    EDV_CHECK(F > 0 && N > 0 && heads > 0, "empty problem");
+    EDV_CHECK(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)dout % 16 == 0) && ((uintptr_t)dqkv % 16 == 0), "16-byte alignment");
+    const long long pairs = (long long)F * N * heads;
+    EDV_CHECK((pairs * 16 + 255) / 256 < (1ll << 31), "grid");
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((pairs * 16 + 255) / 256)), dim3(256), 0, st, dout, out, delta, F, N, heads);
+    EDV_LAUNCH_OK();
+    const long long blocks = (long long)F * heads * ((N + 127) / 128);
+    EDV_CHECK(blocks < (1ll << 31), "grid");
+    hipLaunchKernelGGL(attn_spatial_bwd_kernel<MODE_DQ>, dim3((unsigned)blocks), dim3(256), 0, st, qkv, dout, lse, delta, dqkv, N, heads);
+    EDV_LAUNCH_OK();
+    hipLaunchKernelGGL(attn_spatial_bwd_kernel<MODE_DKV>, dim3((unsigned)blocks), dim3(256), 0, st, qkv, dout, lse, delta, dqkv, N, heads);
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
+}  // namespace edv

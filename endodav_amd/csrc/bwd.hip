@@ -1,0 +1,713 @@
+// Backward (dX) kernels of the HBM-bound operators, plus the low-rank LoRA weight-gradient products.
+// the fine-tune step trains only the LoRA factors (endodav/layers.py:5-34), so every frozen
+// operator needs its input gradient and nothing else.  Layouts are the forward's: channels-last activations, fused
+// q|k|v rows, rows = (frame, token).  Each kernel cites the forward it differentiates.
+#include "ops.hpp"
+
+namespace edv {
+namespace {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// d/dx of 0.5 x (1 + erf(x / sqrt 2)):  Phi(x) + x phi(x)
+__device__ __forceinline__ float gelu_erf_grad(float x) {
+    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+    const float pdf = 0.39894228040143267794f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+// ---- LayerNorm backward (norms.hip layernorm_kernel): one wave per row, dim <= 1024 ------------------------------------
+constexpr int LNB_MAXV = 4;  // float4 chunks per lane
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restrict__ x, RowMap xmap, const float *__restrict__ w,
+                                                            const float *__restrict__ dy, RowMap dymap, float *__restrict__ dx, RowMap dxmap,
+                                                            long long rows, int dim, float eps, int accumulate) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + xmap(row) * dim;
+    const float *gr = dy + dymap(row) * dim;
+    float *dr = dx + dxmap(row) * dim;
+    const int nv = dim >> 2;
+    f32x4 xv[LNB_MAXV], gv[LNB_MAXV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LNB_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        xv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        gv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (c < nv) {
+            xv[i] = *reinterpret_cast<const f32x4 *>(xr + 4 * c);
+            const f32x4 g = *reinterpret_cast<const f32x4 *>(gr + 4 * c);
+            const f32x4 ww = *reinterpret_cast<const f32x4 *>(w + 4 * c);
+            gv[i] = g * ww;
+            s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
+        }
+    }
+    const float mean = wave_sum(s) / (float)dim;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LNB_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            xv[i] -= mean;
+            q += (xv[i].x * xv[i].x + xv[i].y * xv[i].y) + (xv[i].z * xv[i].z + xv[i].w * xv[i].w);
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)dim + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LNB_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            xv[i] *= rstd;  // x-hat
+            s1 += (gv[i].x + gv[i].y) + (gv[i].z + gv[i].w);
+            s2 += (gv[i].x * xv[i].x + gv[i].y * xv[i].y) + (gv[i].z * xv[i].z + gv[i].w * xv[i].w);
+        }
+    }
+    s1 = wave_sum(s1) / (float)dim;
+    s2 = wave_sum(s2) / (float)dim;
+#pragma unroll
+    for (int i = 0; i < LNB_MAXV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            f32x4 o = (gv[i] - s1 - xv[i] * s2) * rstd;
+            if (accumulate) o += *reinterpret_cast<const f32x4 *>(dr + 4 * c);
+            *reinterpret_cast<f32x4 *>(dr + 4 * c) = o;
+        }
+    }
+}
+
+// ---- elementwise ---------------------------------------------------------------------------------------------------------
+// out = (mode 1: d * gelu'(src) | mode 2: src > 0 ? d : 0 | mode 0: d) + (add ? add : 0)
+__global__ __launch_bounds__(256) void ew_bwd_kernel(const float *__restrict__ d, const float *__restrict__ src, const float *__restrict__ add,
+                                                     float *__restrict__ out, long long n4, int mode) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
+        f32x4 v = *reinterpret_cast<const f32x4 *>(d + 4 * i);
+        if (mode) {
+            const f32x4 sv = *reinterpret_cast<const f32x4 *>(src + 4 * i);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = mode == 1 ? v[e] * gelu_erf_grad(sv[e]) : (sv[e] > 0.f ? v[e] : 0.f);
+        }
+        if (add) v += *reinterpret_cast<const f32x4 *>(add + 4 * i);
+        *reinterpret_cast<f32x4 *>(out + 4 * i) = v;
+    }
+}
+
+// GEGLU backward (temporal.hip geglu_kernel): y = a * gelu(g);  x rows are [a (inner) | g (inner)]
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ dx, long long total4,
+                                                        int inner4) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const long long m = i / inner4;
+        const int j = (int)(i - m * inner4);
+        const long long ro = m * (long long)inner4 * 8;
+        const f32x4 a = *reinterpret_cast<const f32x4 *>(x + ro + 4 * j);
+        const f32x4 g = *reinterpret_cast<const f32x4 *>(x + ro + 4 * (inner4 + j));
+        const f32x4 d = *reinterpret_cast<const f32x4 *>(dy + i * 4);
+        f32x4 da, dg;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            da[e] = d[e] * gelu_erf(g[e]);
+            dg[e] = d[e] * a[e] * gelu_erf_grad(g[e]);
+        }
+        *reinterpret_cast<f32x4 *>(dx + ro + 4 * j) = da;
+        *reinterpret_cast<f32x4 *>(dx + ro + 4 * (inner4 + j)) = dg;
+    }
+}
+
+// Wt[k, n] = W[n, k] * (gamma ? gamma[n] : 1): the weight of the dX GEMM  dX = (dY * gamma) W  in the NT form gemm() takes
+__global__ __launch_bounds__(256) void transpose_scale_kernel(const float *__restrict__ W, const float *__restrict__ gamma, float *__restrict__ Wt, int N,
+                                                              int K, int ldw) {
+    __shared__ float tile[32][33];
+    const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, k = k0 + tx;
+        tile[r][tx] = (n < N && k < K) ? W[(long long)n * ldw + k] * (gamma ? gamma[n] : 1.f) : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, n = n0 + tx;
+        if (k < K && n < N) Wt[(long long)k * N + n] = tile[tx][r];
+    }
+}
+
+// ---- low-rank products of the LoRA weight gradients ----------------------------------------------------------------------
+// T[m, j] = sum_k X[m, k] * Wr[j, k],  j < R <= 8: one wave per row
+template <int R>
+__global__ __launch_bounds__(256) void skinny_xwt_kernel(const float *__restrict__ X, long long M, int K, int ldx, const float *__restrict__ Wr,
+                                                         float *__restrict__ T) {
+    const int lane = threadIdx.x & 63;
+    const long long m = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= M) return;
+    const float *xr = X + m * ldx;
+    float acc[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) acc[j] = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(xr + k);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(Wr + (long long)j * K + k);
+            acc[j] += (xv.x * wv.x + xv.y * wv.y) + (xv.z * wv.z + xv.w * wv.w);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j) acc[j] = wave_sum(acc[j]);
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) T[m * R + j] = acc[j];
+    }
+}
+
+// part[s, n, j] = sum_{m in split s} Y[m, n] * T[m, j]:  thread = column n, 4 waves stride the rows of the split
+template <int R>
+__global__ __launch_bounds__(256) void tall_tn_partial_kernel(const float *__restrict__ Y, int ldy, const float *__restrict__ T, long long M, int N,
+                                                              float *__restrict__ part, int rows_per_split) {
+    __shared__ float red[4][64][R];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    const long long mb = (long long)blockIdx.y * rows_per_split;
+    const long long me = mb + rows_per_split < M ? mb + rows_per_split : M;
+    float acc[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) acc[j] = 0.f;
+    if (n < N)
+        for (long long m = mb + wv; m < me; m += 4) {
+            const float y = Y[m * ldy + n];
+#pragma unroll
+            for (int j = 0; j < R; ++j) acc[j] += y * T[m * R + j];
+        }
+#pragma unroll
+    for (int j = 0; j < R; ++j) red[wv][lane][j] = acc[j];
+    __syncthreads();
+    if (wv == 0 && n < N) {
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+            part[((long long)blockIdx.y * N + n) * R + j] = (red[0][lane][j] + red[1][lane][j]) + (red[2][lane][j] + red[3][lane][j]);
+    }
+}
+// out[n, j] = scale * (rowscale ? rowscale[n] : 1) * sum_s part[s, n, j]   (fixed order: deterministic)
+__global__ __launch_bounds__(256) void tall_tn_reduce_kernel(const float *__restrict__ part, int splits, int N, int R, float scale,
+                                                             const float *__restrict__ rowscale, float *__restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= N * R) return;
+    float s = 0.f;
+    for (int sp = 0; sp < splits; ++sp) s += part[(long long)sp * N * R + i];
+    out[i] = s * scale * (rowscale ? rowscale[i / R] : 1.f);
+}
+
+// LoRA factor gradients from dBp [out, r] (= s dY^T (X A'^T)) and dApT [in, r] (= s X^T (dY B')), mylora/layers.py:148-157, 384-393.
+//   lora:   dB = dBp,            dA[j, k] = dApT[k, j]
+//   dvlora: dB = dBp * V, dV = dBp * B;  dA = dApT^T * U, dU = dApT^T * A        (A' = A * U, B' = B * V elementwise)
+__global__ __launch_bounds__(256) void lora_grad_finalize_kernel(const float *__restrict__ dBp, const float *__restrict__ dApT, const float *__restrict__ A,
+                                                                 const float *__restrict__ Bm, const float *__restrict__ U, const float *__restrict__ V,
+                                                                 float *__restrict__ dA, float *__restrict__ dB, float *__restrict__ dU,
+                                                                 float *__restrict__ dV, int nout, int nin, int r) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < nout * r) {
+        const float g = dBp[i];
+        if (V) {
+            if (dB) dB[i] = g * V[i];
+            if (dV) dV[i] = g * Bm[i];
+        } else if (dB) {
+            dB[i] = g;
+        }
+    }
+    if (i < r * nin) {
+        const int j = i / nin, k = i - j * nin;
+        const float g = dApT[k * r + j];
+        if (U) {
+            if (dA) dA[i] = g * U[i];
+            if (dU) dU[i] = g * A[i];
+        } else if (dA) {
+            dA[i] = g;
+        }
+    }
+}
+
+// ---- bilinear, align_corners=True, backward as a deterministic gather (resample.hip bilinear_*) ---------------------------
+// forward: src = (in-1)/(out-1) * o (rounded float product), i0 = floor(src), lam = src - i0, i1 = min(i0+1, in-1)
+__device__ __forceinline__ void bl_src(int o, float ratio, int in, int out, int &i0, int &i1, float &lam) {
+    if (in == out) {
+        i0 = i1 = o;
+        lam = 0.f;
+        return;
+    }
+    const float s = __fmul_rn(ratio, (float)o);  // the forward's rounded product (resample.hip lin_coord)
+    i0 = (int)s;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    lam = fminf(fmaxf(__fsub_rn(s, (float)i0), 0.f), 1.f);
+}
+// weight of output coordinate o on input coordinate i
+__device__ __forceinline__ float bl_weight(int o, int i, float ratio, int in, int out) {
+    int i0, i1;
+    float lam;
+    bl_src(o, ratio, in, out, i0, i1, lam);
+    float w = 0.f;
+    if (i0 == i) w += 1.f - lam;
+    if (i1 == i) w += lam;
+    return w;
+}
+// one thread per (frame, iy, ix, channel chunk of 4 or 1)
+template <int V>
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float *__restrict__ dy, float *__restrict__ dx, int F, int ih, int iw, int C, int oh, int ow,
+                                                           float ry, float rx, int accumulate) {
+    const int cv = C / V;
+    const long long total = (long long)F * ih * iw * cv;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int c = (int)(gid % cv) * V;
+    long long r = gid / cv;
+    const int ix = (int)(r % iw);
+    r /= iw;
+    const int iy = (int)(r % ih);
+    const int f = (int)(r / ih);
+    // candidate output range: src in (i-1, i+1)  <=>  o in ((i-1)/ratio, (i+1)/ratio); widened by one and tested exactly
+    auto range = [](int i, float ratio, int out, int &lo, int &hi) {
+        if (ratio <= 0.f) {  // in == 1 or out == 1: every output reads input 0
+            lo = 0;
+            hi = out - 1;
+            return;
+        }
+        lo = (int)floorf((float)(i - 1) / ratio) - 1;
+        hi = (int)ceilf((float)(i + 1) / ratio) + 1;
+        lo = lo < 0 ? 0 : lo;
+        hi = hi > out - 1 ? out - 1 : hi;
+    };
+    int ylo, yhi, xlo, xhi;
+    range(iy, ry, oh, ylo, yhi);
+    range(ix, rx, ow, xlo, xhi);
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+    for (int oy = ylo; oy <= yhi; ++oy) {
+        const float wy = bl_weight(oy, iy, ry, ih, oh);
+        if (wy == 0.f) continue;
+        for (int ox = xlo; ox <= xhi; ++ox) {
+            const float wgt = wy * bl_weight(ox, ix, rx, iw, ow);
+            if (wgt == 0.f) continue;
+            const float *p = dy + (((long long)f * oh + oy) * ow + ox) * C + c;
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] += wgt * p[e];
+        }
+    }
+    float *q = dx + (((long long)f * ih + iy) * iw + ix) * C + c;
+#pragma unroll
+    for (int e = 0; e < V; ++e) q[e] = accumulate ? q[e] + acc[e] : acc[e];
+}
+
+// final 1x1 conv to one channel + ReLU (resample.hip dot_channels), input o2 is itself post-ReLU:
+//   d_o2[p, c] = (disp[p] > 0 ? g[p] : 0) * w[c] * (o2[p, c] > 0)
+__global__ __launch_bounds__(256) void dot_channels_bwd_kernel(const float *__restrict__ g, const float *__restrict__ disp, const float *__restrict__ w,
+                                                               const float *__restrict__ o2, float *__restrict__ d_o2, long long npix, int C) {
+    const int c4n = C >> 2;
+    const long long total = npix * c4n;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long p = i / c4n;
+        const int c = (int)(i - p * c4n) * 4;
+        const float gz = disp[p] > 0.f ? g[p] : 0.f;
+        const f32x4 o = *reinterpret_cast<const f32x4 *>(o2 + i * 4);
+        const f32x4 ww = *reinterpret_cast<const f32x4 *>(w + c);
+        f32x4 d;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = o[e] > 0.f ? gz * ww[e] : 0.f;
+        *reinterpret_cast<f32x4 *>(d_o2 + i * 4) = d;
+    }
+}
+
+// ---- GroupNorm backward (norms.hip groupnorm_*): sums per (frame, group), then apply ------------------------------------
+__global__ __launch_bounds__(256) void groupnorm_bwd_sums_kernel(const float *__restrict__ x, const float *__restrict__ stats, const float *__restrict__ w,
+                                                                 const float *__restrict__ dy, float *__restrict__ sums, int P, int C, int groups) {
+    __shared__ float red[2][4];
+    const int f = blockIdx.y, g = blockIdx.x, cg = C / groups;
+    const long long base = (long long)f * P * C + g * cg;
+    const int n = P * cg;
+    const float mean = stats[((long long)f * groups + g) * 2], rstd = stats[((long long)f * groups + g) * 2 + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float s1 = 0.f, s2 = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int p = i / cg, c = i - p * cg;
+        const long long o = base + (long long)p * C + c;
+        const float gy = dy[o] * w[g * cg + c];
+        s1 += gy;
+        s2 += gy * (x[o] - mean) * rstd;
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) {
+        red[0][wv] = s1;
+        red[1][wv] = s2;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sums[((long long)f * groups + g) * 2 + 0] = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / (float)n;
+        sums[((long long)f * groups + g) * 2 + 1] = ((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / (float)n;
+    }
+}
+__global__ __launch_bounds__(256) void groupnorm_bwd_apply_kernel(const float *__restrict__ x, const float *__restrict__ stats, const float *__restrict__ w,
+                                                                  const float *__restrict__ dy, const float *__restrict__ sums, float *__restrict__ dx,
+                                                                  long long total4, int P, int C, int groups, int accumulate) {
+    const int cg = C / groups, c4n = C >> 2;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const long long pix = i / c4n;
+        const int c = (int)(i - pix * c4n) * 4;
+        const long long f = pix / P;
+        const f32x4 xv = *reinterpret_cast<const f32x4 *>(x + i * 4);
+        const f32x4 gv = *reinterpret_cast<const f32x4 *>(dy + i * 4);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ch = c + e, g = ch / cg;
+            const long long sg = (f * groups + g) * 2;
+            const float mean = stats[sg], rstd = stats[sg + 1];
+            const float xh = (xv[e] - mean) * rstd;
+            o[e] = (gv[e] * w[ch] - sums[sg] - xh * sums[sg + 1]) * rstd;
+        }
+        if (accumulate) o += *reinterpret_cast<const f32x4 *>(dx + i * 4);
+        *reinterpret_cast<f32x4 *>(dx + i * 4) = o;
+    }
+}
+
+// ---- temporal attention backward (temporal.hip attn_temporal_kernel): one thread per (clip, pixel, head), all T queries --
+template <int TMAX>
+__global__ __launch_bounds__(64) void attn_temporal_bwd_kernel(const float *__restrict__ qkv, const float *__restrict__ dout, float *__restrict__ dqkv, int B,
+                                                               int T, int P, int C, int heads, float scale) {
+    const long long total = (long long)B * P * heads;
+    const long long gid = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (gid >= total) return;
+    const int head = (int)(gid % heads);
+    long long r = gid / heads;
+    const int p = (int)(r % P);
+    const int b = (int)(r / P);
+    const int d = C / heads, C3 = 3 * C;
+    const long long ts3 = (long long)P * C3, ts1 = (long long)P * C;
+    const float *qb = qkv + ((long long)(b * T) * P + p) * C3 + head * d;
+    const float *kb = qb + C, *vb = qb + 2 * C;
+    const float *gb = dout + ((long long)(b * T) * P + p) * C + head * d;
+    float *dqb = dqkv + ((long long)(b * T) * P + p) * C3 + head * d;
+    float *dkb = dqb + C, *dvb = dqb + 2 * C;
+    // dK and dV rows accumulate over the queries: zero them first (this thread owns them)
+    for (int t = 0; t < T; ++t)
+        for (int c = 0; c < d; ++c) {
+            dkb[t * ts3 + c] = 0.f;
+            dvb[t * ts3 + c] = 0.f;
+        }
+    for (int tq = 0; tq < T; ++tq) {
+        float s[TMAX], dp[TMAX];
+#pragma unroll
+        for (int ts = 0; ts < TMAX; ++ts) s[ts] = dp[ts] = 0.f;
+        for (int c = 0; c < d; ++c) {
+            const float q = qb[tq * ts3 + c], g = gb[tq * ts1 + c];
+#pragma unroll
+            for (int ts = 0; ts < TMAX; ++ts)
+                if (ts < T) {
+                    s[ts] += q * kb[ts * ts3 + c];
+                    dp[ts] += g * vb[ts * ts3 + c];
+                }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int ts = 0; ts < TMAX; ++ts)
+            if (ts < T) {
+                s[ts] *= scale;
+                mx = fmaxf(mx, s[ts]);
+            }
+        float sum = 0.f;
+#pragma unroll
+        for (int ts = 0; ts < TMAX; ++ts)
+            if (ts < T) {
+                s[ts] = expf(s[ts] - mx);
+                sum += s[ts];
+            }
+        const float inv = 1.0f / sum;
+        float dot = 0.f;
+#pragma unroll
+        for (int ts = 0; ts < TMAX; ++ts)
+            if (ts < T) {
+                s[ts] *= inv;  // P
+                dot += s[ts] * dp[ts];
+            }
+#pragma unroll
+        for (int ts = 0; ts < TMAX; ++ts)
+            if (ts < T) dp[ts] = s[ts] * (dp[ts] - dot) * scale;  // dS * scale
+        for (int c = 0; c < d; ++c) {
+            const float q = qb[tq * ts3 + c], g = gb[tq * ts1 + c];
+            float dq = 0.f;
+#pragma unroll
+            for (int ts = 0; ts < TMAX; ++ts)
+                if (ts < T) {
+                    dq += dp[ts] * kb[ts * ts3 + c];
+                    dkb[ts * ts3 + c] += dp[ts] * q;
+                    dvb[ts * ts3 + c] += s[ts] * g;
+                }
+            dqb[tq * ts3 + c] = dq;
+        }
+    }
+}
+
+// pixel-unshuffle of a ConvTranspose(k = s) output gradient: dy [F, h*s, w*s, C] -> A [F*h*w, s*s*C] with column
+// (dy*s + dx)*C + co, the row order of the packed forward weight (prep.hip pack_convT)
+__global__ __launch_bounds__(256) void pixel_unshuffle_kernel(const float *__restrict__ dy, float *__restrict__ A, int F, int h, int w, int C, int s) {
+    const int c4n = C >> 2;
+    const long long total = (long long)F * h * w * s * s * c4n;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % c4n) * 4;
+        long long r = i / c4n;
+        const int sub = (int)(r % (s * s));
+        r /= (s * s);
+        const int x = (int)(r % w);
+        r /= w;
+        const int y = (int)(r % h);
+        const int f = (int)(r / h);
+        const int dyy = sub / s, dxx = sub - dyy * s;
+        const float *src = dy + ((((long long)f * h * s + (long long)y * s + dyy) * (w * s)) + (long long)x * s + dxx) * C + c;
+        *reinterpret_cast<f32x4 *>(A + i * 4) = *reinterpret_cast<const f32x4 *>(src);
+    }
+}
+
+// 3x3 stride-2 pad-1 convolution, input gradient, direct form (only head.resize_layers.3: a 19x19 -> 10x10 map).
+// w packed [Cout][3][3][Cin] (prep.hip pack_conv3x3); dy [F, OH, OW, Cout]; dx [F, H, W, Cin]
+__global__ __launch_bounds__(256) void conv3x3_s2_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ wp, float *__restrict__ dx, int F, int H,
+                                                             int W, int Cin, int Cout, int OH, int OW) {
+    const long long total = (long long)F * H * W * Cin;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int ci = (int)(gid % Cin);
+    long long r = gid / Cin;
+    const int x = (int)(r % W);
+    r /= W;
+    const int y = (int)(r % H);
+    const int f = (int)(r / H);
+    float acc = 0.f;
+    for (int ky = 0; ky < 3; ++ky) {
+        const int ty = y + 1 - ky;  // = 2 * oy
+        if (ty < 0 || (ty & 1)) continue;
+        const int oy = ty >> 1;
+        if (oy >= OH) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int tx = x + 1 - kx;
+            if (tx < 0 || (tx & 1)) continue;
+            const int ox = tx >> 1;
+            if (ox >= OW) continue;
+            const float *g = dy + (((long long)f * OH + oy) * OW + ox) * Cout;
+            const float *wk = wp + ((long long)(ky * 3 + kx)) * Cin + ci;
+            for (int co = 0; co < Cout; ++co) acc += g[co] * wk[(long long)co * 9 * Cin];
+        }
+    }
+    dx[gid] = acc;
+}
+
+// w [Cout, Cin, 3, 3] -> the packed weight of the stride-1 input-gradient convolution: [Cin][3][3][Cout], taps flipped
+__global__ __launch_bounds__(256) void pack_conv3x3_bwd_kernel(const float *__restrict__ w, float *__restrict__ out, int Cout, int Cin) {
+    const int total = Cout * Cin * 9;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int co = i % Cout;
+    int r = i / Cout;
+    const int tap = r % 9;
+    const int ci = r / 9;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    out[i] = w[(((long long)co * Cin + ci) * 3 + (2 - ky)) * 3 + (2 - kx)];
+}
+
+// Aeff [r, nin] = A * U;  BgT [r, nout] = (B * V * gamma)^T   (U, V, gamma optional)
+__global__ __launch_bounds__(256) void lora_factors_kernel(const float *__restrict__ A, const float *__restrict__ Bm, const float *__restrict__ U,
+                                                           const float *__restrict__ V, const float *__restrict__ gamma, float *__restrict__ Aeff,
+                                                           float *__restrict__ BgT, int nout, int nin, int r) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < r * nin) Aeff[i] = A[i] * (U ? U[i] : 1.f);
+    if (i < r * nout) {
+        const int j = i / nout, n = i - j * nout;
+        BgT[i] = Bm[n * r + j] * (V ? V[n * r + j] : 1.f) * (gamma ? gamma[n] : 1.f);
+    }
+}
+
+int ew_blocks(long long n) { return (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); }
+
+}  // namespace
+
+int layernorm_bwd(const float *x, RowMap xmap, const float *w, const float *dy, RowMap dymap, float *dx, RowMap dxmap, long long rows, int dim, float eps,
+                  bool accumulate, hipStream_t st) {
+    EDV_CHECK(x && w && dy && dx, "null operand");
+    EDV_CHECK(rows > 0 && dim % 4 == 0 && dim <= 256 * LNB_MAXV, "dim must be a multiple of 4 and <= 1024");
+    const long long blocks = (rows + 3) / 4;
+    EDV_CHECK(blocks < (1ll << 31), "grid");
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, xmap, w, dy, dymap, dx, dxmap, rows, dim, eps, accumulate ? 1 : 0);
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
+int ew_bwd(const float *d, const float *src, const float *add, float *out, long long n, int mode, hipStream_t st) {
+    EDV_CHECK(d && out && n > 0 && n % 4 == 0, "shape");
+    EDV_CHECK(mode >= 0 && mode <= 2 && (mode == 0 || src), "mode");
+    hipLaunchKernelGGL(ew_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, st, d, src, add, out, n / 4, mode);
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
+int geglu_bwd(const float *x, const float *dy, float *dx, long long M, int inner, hipStream_t st) {
+    EDV_CHECK(x && dy && dx && M > 0 && inner > 0 && inner % 4 == 0, "shape");
+    const long long total4 = M * (inner / 4);
+    hipLaunchKernelGGL(geglu_bwd_kernel, dim3(ew_blocks(total4)), dim3(256), 0, st, x, dy, dx, total4, inner / 4);
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
+int transpose_scale(const float *W, int ldw, const float *gamma, float *Wt, int N, int K, hipStream_t st) {
+    EDV_CHECK(W && Wt && N > 0 && K > 0 && ldw >= K, "shape");
+    hipLaunchKernelGGL(transpose_scale_kernel, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, st, W, gamma, Wt, N, K, ldw);
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
+int skinny_xwt(const float *X, long long M, int K, int ldx, const float *Wr, int r, float *T, hipStream_t st) {
+    EDV_CHECK(X && Wr && T && M > 0 && K > 0 && K % 4 == 0 && ldx % 4 == 0, "shape");
+    EDV_CHECK(r == 1 || r == 2 || r == 4 || r == 8, "rank must be 1, 2, 4 or 8");
+    const long long blocks = (M + 3) / 4;
+    EDV_CHECK(blocks < (1ll << 31), "grid");
+    dim3 grid((unsigned)blocks), block(256);
+    switch (r) {
+        case 1: hipLaunchKernelGGL(skinny_xwt_kernel<1>, grid, block, 0, st, X, M, K, ldx, Wr, T); break;
+        case 2: hipLaunchKernelGGL(skinny_xwt_kernel<2>, grid, block, 0, st, X, M, K, ldx, Wr, T); break;
+        case 4: hipLaunchKernelGGL(skinny_xwt_kernel<4>, grid, block, 0, st, X, M, K, ldx, Wr, T); break;
+        default: hipLaunchKernelGGL(skinny_xwt_kernel<8>, grid, block, 0, st, X, M, K, ldx, Wr, T); break;
+    }
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
+size_t tall_tn_workspace(int N, int r) { return (size_t)TALL_SPLITS * N * r; }
+
+int tall_tn(const float *Y, int ldy, const float *T, long long M, int N, int r, float scale, const float *rowscale, float *part, float *out, hipStream_t st) {
+    EDV_CHECK(Y && T && part && out && M > 0 && N > 0, "shape");
+    EDV_CHECK(r == 1 || r == 2 || r == 4 || r == 8, "rank must be 1, 2, 4 or 8");
+    const int rows_per_split = (int)((M + TALL_SPLITS - 1) / TALL_SPLITS);
+    const int splits = (int)((M + rows_per_split - 1) / rows_per_split);
+    dim3 grid((N + 63) / 64, splits), block(256);
+    switch (r) {
+        case 1: hipLaunchKernelGGL(tall_tn_partial_kernel<1>, grid, block, 0, st, Y, ldy, T, M, N, part, rows_per_split); break;
+        case 2: hipLaunchKernelGGL(tall_tn_partial_kernel<2>, grid, block, 0, st, Y, ldy, T, M, N, part, rows_per_split); break;
+        case 4: hipLaunchKernelGGL(tall_tn_partial_kernel<4>, grid, block, 0, st, Y, ldy, T, M, N, part, rows_per_split); break;
+        default: hipLaunchKernelGGL(tall_tn_partial_kernel<8>, grid, block, 0, st, Y, ldy, T, M, N, part, rows_per_split); break;
+    }
+    EDV_LAUNCH_OK();
+    hipLaunchKernelGGL(tall_tn_reduce_kernel, dim3((N * r + 255) / 256), dim3(256), 0, st, part, splits, N, r, scale, rowscale, out);
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
+int lora_grad_finalize(const float *dBp, const float *dApT, const float *A, const float *Bm, const float *U, const float *V, float *dA, float *dB, float *dU,
+                       float *dV, int nout, int nin, int r, hipStream_t st) {
+    EDV_CHECK(dBp && dApT && nout > 0 && nin > 0 && r > 0, "shape");
+    EDV_CHECK((U == nullptr) == (V == nullptr), "U and V come together");
+    EDV_CHECK(!U || (A && Bm), "dvlora needs A and B");
+    const int n = (nout > nin ? nout : nin) * r;
+    hipLaunchKernelGGL(lora_grad_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dBp, dApT, A, Bm, U, V, dA, dB, dU, dV, nout, nin, r);
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
+size_t lora_grads_workspace(long long M, int nin, int nout, int r) {
+    const int nmax = nin > nout ? nin : nout;
+    return (size_t)2 * M * r + (size_t)r * (nin + nout) + tall_tn_workspace(nmax, r) + (size_t)r * (nin + nout) + 64;
+}
+
+// Gradients of the LoRA factors of y = gamma * (x (W + s B' A')^T + b), A' = A*U, B' = B*V (mylora/layers.py:148-157,
+// 384-393), given x [M, nin] and G = dL/dy [M, nout]:   dB' = s gamma (G^T (x A'^T)),   dA' = s (G gamma B')^T x.
+int lora_grads(const float *X, int ldx, const float *G, int ldg, long long M, int nin, int nout, int r, const float *A, const float *Bm, const float *U,
+               const float *V, float s, const float *gamma, float *ws, size_t ws_floats, float *dA, float *dB, float *dU, float *dV, hipStream_t st) {
+    EDV_CHECK(X && G && A && Bm && ws, "null operand");
+    EDV_CHECK(ws_floats >= lora_grads_workspace(M, nin, nout, r), "workspace too small (lora_grads_workspace)");
+    float *t = ws, *u = t + M * r, *Aeff = u + M * r, *BgT = Aeff + (size_t)r * nin;
+    float *part = BgT + (size_t)r * nout;
+    float *dBp = part + tall_tn_workspace(nin > nout ? nin : nout, r), *dApT = dBp + (size_t)r * nout;
+    const int nf = r * (nin > nout ? nin : nout);
+    hipLaunchKernelGGL(lora_factors_kernel, dim3((nf + 255) / 256), dim3(256), 0, st, A, Bm, U, V, gamma, Aeff, BgT, nout, nin, r);
+    EDV_LAUNCH_OK();
+    EDV_TRY(skinny_xwt(X, M, nin, ldx, Aeff, r, t, st));
+    EDV_TRY(skinny_xwt(G, M, nout, ldg, BgT, r, u, st));
+    EDV_TRY(tall_tn(G, ldg, t, M, nout, r, s, gamma, part, dBp, st));
+    EDV_TRY(tall_tn(X, ldx, u, M, nin, r, s, nullptr, part, dApT, st));
+    return lora_grad_finalize(dBp, dApT, A, Bm, U, V, dA, dB, dU, dV, nout, nin, r, st);
+}
+
+int bilinear_bwd(const float *dy, float *dx, int F, int ih, int iw, int C, int oh, int ow, bool accumulate, hipStream_t st) {
+    EDV_CHECK(dy && dx && F > 0 && ih > 0 && iw > 0 && C > 0 && oh > 0 && ow > 0, "shape");
+    const float ry = oh > 1 ? (float)(ih - 1) / (float)(oh - 1) : 0.f, rx = ow > 1 ? (float)(iw - 1) / (float)(ow - 1) : 0.f;
+    if (C % 4 == 0) {
+        const long long total = (long long)F * ih * iw * (C / 4);
+        EDV_CHECK((total + 255) / 256 < (1ll << 31), "grid");
+        hipLaunchKernelGGL(bilinear_bwd_kernel<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, dx, F, ih, iw, C, oh, ow, ry, rx, accumulate ? 1 : 0);
+    } else {
+        const long long total = (long long)F * ih * iw * C;
+        EDV_CHECK((total + 255) / 256 < (1ll << 31), "grid");
+        hipLaunchKernelGGL(bilinear_bwd_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, dx, F, ih, iw, C, oh, ow, ry, rx, accumulate ? 1 : 0);
+    }
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
+int dot_channels_bwd(const float *g, const float *disp, const float *w, const float *o2, float *d_o2, long long npix, int C, hipStream_t st) {
+    EDV_CHECK(g && disp && w && o2 && d_o2 && npix > 0 && C % 4 == 0, "shape");
+    hipLaunchKernelGGL(dot_channels_bwd_kernel, dim3(ew_blocks(npix * (C / 4))), dim3(256), 0, st, g, disp, w, o2, d_o2, npix, C);
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
+int groupnorm_bwd(const float *x, const float *stats, const float *w, const float *dy, float *sums, float *dx, int F, int P, int C, int groups, bool accumulate,
+                  hipStream_t st) {
+    EDV_CHECK(x && stats && w && dy && sums && dx, "null operand");
+    EDV_CHECK(F > 0 && F <= 65535 && P > 0 && C > 0 && groups > 0 && C % groups == 0 && C % 4 == 0, "shape");
+    hipLaunchKernelGGL(groupnorm_bwd_sums_kernel, dim3(groups, F), dim3(256), 0, st, x, stats, w, dy, sums, P, C, groups);
+    EDV_LAUNCH_OK();
+    const long long total4 = (long long)F * P * C / 4;
+    hipLaunchKernelGGL(groupnorm_bwd_apply_kernel, dim3(ew_blocks(total4)), dim3(256), 0, st, x, stats, w, dy, sums, dx, total4, P, C, groups, accumulate ? 1 : 0);
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
+int attn_temporal_bwd(const float *qkv, const float *dout, float *dqkv, int B, int T, int P, int C, int heads, hipStream_t st) {
+    EDV_CHECK(qkv && dout && dqkv, "null operand");
+    EDV_CHECK(B > 0 && T > 0 && T <= 32 && P > 0 && C > 0 && heads > 0 && C % heads == 0, "shape");
+    const long long total = (long long)B * P * heads;
+    const long long blocks = (total + 63) / 64;
+    EDV_CHECK(blocks < (1ll << 31), "grid");
+    const float scale = 1.0f / sqrtf((float)(C / heads));
+    dim3 grid((unsigned)blocks), block(64);
+    if (T <= 8)
+        hipLaunchKernelGGL(attn_temporal_bwd_kernel<8>, grid, block, 0, st, qkv, dout, dqkv, B, T, P, C, heads, scale);
+    else if (T <= 16)
+        hipLaunchKernelGGL(attn_temporal_bwd_kernel<16>, grid, block, 0, st, qkv, dout, dqkv, B, T, P, C, heads, scale);
+    else
+        hipLaunchKernelGGL(attn_temporal_bwd_kernel<32>, grid, block, 0, st, qkv, dout, dqkv, B, T, P, C, heads, scale);
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
+int pixel_unshuffle(const float *dy, float *A, int F, int h, int w, int C, int s, hipStream_t st) {
+    EDV_CHECK(dy && A && F > 0 && h > 0 && w > 0 && C % 4 == 0 && s > 0, "shape");
+    const long long total = (long long)F * h * w * s * s * (C / 4);
+    hipLaunchKernelGGL(pixel_unshuffle_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, dy, A, F, h, w, C, s);
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
+int conv3x3_s2_bwd(const float *dy, const float *wpacked, float *dx, int F, int H, int W, int Cin, int Cout, hipStream_t st) {
+    EDV_CHECK(dy && wpacked && dx && F > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "shape");
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const long long total = (long long)F * H * W * Cin;
+    EDV_CHECK((total + 255) / 256 < (1ll << 31), "grid");
+    hipLaunchKernelGGL(conv3x3_s2_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, wpacked, dx, F, H, W, Cin, Cout, OH, OW);
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
+int pack_conv3x3_bwd(const float *w, float *out, int Cout, int Cin, hipStream_t st) {
+    EDV_CHECK(w && out && Cout > 0 && Cin > 0, "shape");
+    const int total = Cout * Cin * 9;
+    hipLaunchKernelGGL(pack_conv3x3_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, out, Cout, Cin);
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
+}  // namespace edv

@@ -68,7 +68,10 @@ const char *gemm_kernel_name(const GemmDesc &d);
 // attention (attn_spatial.hip, temporal.hip)
 // ------------------------------------------------------------------------------------------
 size_t attn_spatial_workspace(int F, int N, int heads);  // floats
-int attn_spatial(const float *qkv, float *out, int F, int N, int heads, float *ws, size_t ws_floats, hipStream_t st);
+// lse (optional, [F, heads, N]): per-row log-sum-exp of the scores in base 2, for attn_spatial_bwd
+int attn_spatial(const float *qkv, float *out, int F, int N, int heads, float *ws, size_t ws_floats, hipStream_t st, float *lse = nullptr);
+int attn_spatial_bwd(const float *qkv, const float *out, const float *dout, const float *lse, float *delta, float *dqkv, int F, int N, int heads,
+                     hipStream_t st);
 int attn_temporal(const float *qkv, float *out, int B, int T, int P, int C, int heads, hipStream_t st);
 int geglu(const float *x, float *y, long long M, int inner, hipStream_t st);
 
@@ -106,5 +109,32 @@ int fold_lora(const float *W, const float *A, const float *B, const float *U, co
 int fold_ssb(const float *W, const float *a, const float *b, float *out, int nout, int nin, hipStream_t st);
 // W_eff += Utop diag(idx) Vtop  (DashLinear after warm-up)
 int fold_dash(const float *Utop, const float *idx, const float *Vtop, float *inout, int nout, int nin, int r, hipStream_t st);
+
+// ------------------------------------------------------------------------------------------
+// backward (bwd.hip, attn_spatial_bwd.hip): input gradients of the frozen operators + LoRA factor gradients
+int layernorm_bwd(const float *x, RowMap xmap, const float *w, const float *dy, RowMap dymap, float *dx, RowMap dxmap, long long rows, int dim, float eps,
+                  bool accumulate, hipStream_t st);
+// out = f(d) + (add ? add : 0);  mode 0: f = d, 1: d * gelu'(src), 2: src > 0 ? d : 0
+int ew_bwd(const float *d, const float *src, const float *add, float *out, long long n, int mode, hipStream_t st);
+int geglu_bwd(const float *x, const float *dy, float *dx, long long M, int inner, hipStream_t st);
+int transpose_scale(const float *W, int ldw, const float *gamma, float *Wt, int N, int K, hipStream_t st);  // Wt[k,n] = W[n,k] * gamma[n]
+int skinny_xwt(const float *X, long long M, int K, int ldx, const float *Wr, int r, float *T, hipStream_t st);  // T[M,r] = X Wr^T, Wr [r,K]
+constexpr int TALL_SPLITS = 64;
+size_t tall_tn_workspace(int N, int r);  // floats
+// out[N,r] = scale * rowscale[n] * sum_m Y[m,n] T[m,j]   (deterministic two-stage reduction)
+int tall_tn(const float *Y, int ldy, const float *T, long long M, int N, int r, float scale, const float *rowscale, float *part, float *out, hipStream_t st);
+int lora_grad_finalize(const float *dBp, const float *dApT, const float *A, const float *Bm, const float *U, const float *V, float *dA, float *dB, float *dU,
+                       float *dV, int nout, int nin, int r, hipStream_t st);
+size_t lora_grads_workspace(long long M, int nin, int nout, int r);  // floats
+int lora_grads(const float *X, int ldx, const float *G, int ldg, long long M, int nin, int nout, int r, const float *A, const float *Bm, const float *U,
+               const float *V, float s, const float *gamma, float *ws, size_t ws_floats, float *dA, float *dB, float *dU, float *dV, hipStream_t st);
+int bilinear_bwd(const float *dy, float *dx, int F, int ih, int iw, int C, int oh, int ow, bool accumulate, hipStream_t st);
+int dot_channels_bwd(const float *g, const float *disp, const float *w, const float *o2, float *d_o2, long long npix, int C, hipStream_t st);
+int groupnorm_bwd(const float *x, const float *stats, const float *w, const float *dy, float *sums, float *dx, int F, int P, int C, int groups, bool accumulate,
+                  hipStream_t st);
+int attn_temporal_bwd(const float *qkv, const float *dout, float *dqkv, int B, int T, int P, int C, int heads, hipStream_t st);
+int pixel_unshuffle(const float *dy, float *A, int F, int h, int w, int C, int s, hipStream_t st);
+int conv3x3_s2_bwd(const float *dy, const float *wpacked, float *dx, int F, int H, int W, int Cin, int Cout, hipStream_t st);
+int pack_conv3x3_bwd(const float *w, float *out, int Cout, int Cin, hipStream_t st);  // [Co,Ci,3,3] -> [Ci][3][3][Co], taps flipped
 
 }  // namespace edv

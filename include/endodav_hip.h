@@ -149,7 +149,12 @@ int edv_pack_conv3x3(const float *w_dev, float *wpacked_dev, int32_t Cout, int32
  * owned by the caller, one per concurrently running call). */
 size_t edv_attn_spatial_workspace(int32_t F, int32_t N, int32_t heads);
 int edv_attn_spatial(const float *qkv_dev, float *out_dev, int32_t F, int32_t N, int32_t heads, float *workspace_dev,
-                     size_t workspace_bytes, void *stream);
+                     size_t workspace_bytes, float *lse_dev, void *stream);
+/* lse_dev (optional, [F, heads, N]): per-row log-sum-exp of the scaled scores in base 2, the only extra state the
+ * backward needs.  edv_attn_spatial_bwd: dqkv [F*N, 3*heads*64] (like qkv) from qkv, out, dout [F*N, heads*64] and lse;
+ * delta_dev is [F, heads, N] floats of scratch. */
+int edv_attn_spatial_bwd(const float *qkv_dev, const float *out_dev, const float *dout_dev, const float *lse_dev, float *delta_dev,
+                         float *dqkv_dev, int32_t F, int32_t N, int32_t heads, void *stream);
 
 /* Temporal attention core, motion_module.py:230-297 + attention.py:182-211: qkv [B*T*P, 3C]
  * (q|k|v per row, 8 heads), softmax over the T frames of each pixel -> out [B*T*P, C]. */
@@ -190,6 +195,43 @@ int edv_resize_bicubic(const float *x_dev, float *y_dev, int32_t planes, int32_t
 /* out = W + scale * (B∘V)(A∘U)  (U, V may be NULL): the LoRA / DV-LoRA fold of mylora/layers.py:148-157,384-393. */
 int edv_fold_lora(const float *W_dev, const float *A_dev, const float *B_dev, const float *U_dev, const float *V_dev, float scale, float *out_dev,
                   int32_t nout, int32_t nin, int32_t r, void *stream);
+
+/* ---- backward (fine-tune step): input gradients of the frozen operators and the gradients of the
+ * LoRA factors, the only trainable tensors (endodav/layers.py:5-34).  Same layouts as the forward kernels. ---- */
+/* LayerNorm (no affine gradient): dx (+)= dLN(x; w, eps)(dy);  rows x dim, dim % 4 == 0, dim <= 1024. */
+int edv_layernorm_bwd(const float *x_dev, const float *w_dev, const float *dy_dev, float *dx_dev, int64_t rows, int32_t dim, float eps,
+                      int32_t accumulate, void *stream);
+/* out = f(d) + (add ? add : 0); mode 0: f = d; 1: d * gelu'(src) (exact erf form); 2: src > 0 ? d : 0.  n % 4 == 0. */
+int edv_ew_bwd(const float *d_dev, const float *src_dev, const float *add_dev, float *out_dev, int64_t n, int32_t mode, void *stream);
+/* GEGLU (attention.py:363-384): x [M, 2*inner] = [a | g], y = a * gelu(g); dx from dy [M, inner]. */
+int edv_geglu_bwd(const float *x_dev, const float *dy_dev, float *dx_dev, int64_t M, int32_t inner, void *stream);
+/* Wt[k, n] = W[n, k] * gamma[n] (gamma may be NULL): the NT-form weight of dX = (dY * gamma) W. */
+int edv_transpose_scale(const float *W_dev, const float *gamma_dev, float *Wt_dev, int32_t N, int32_t K, void *stream);
+/* LoRA / DV-LoRA factor gradients of y = gamma * (x (W + s (B*V)(A*U))^T + b) from x [M, nin] and G = dL/dy [M, nout]
+ * (mylora/layers.py:148-157, 384-393).  U/V NULL = plain LoRA; gamma may be NULL; any output may be NULL.  r in {1,2,4,8}. */
+size_t edv_lora_grads_workspace(int64_t M, int32_t nin, int32_t nout, int32_t r); /* bytes */
+int edv_lora_grads(const float *x_dev, const float *g_dev, int64_t M, int32_t nin, int32_t nout, int32_t r, const float *A_dev, const float *B_dev,
+                   const float *U_dev, const float *V_dev, float s, const float *gamma_dev, float *workspace_dev, size_t workspace_bytes, float *dA_dev,
+                   float *dB_dev, float *dU_dev, float *dV_dev, void *stream);
+/* bilinear align_corners=True, input gradient: dy [F,oh,ow,C] -> dx [F,ih,iw,C] (deterministic gather). */
+int edv_bilinear_bwd(const float *dy_dev, float *dx_dev, int32_t F, int32_t ih, int32_t iw, int32_t C, int32_t oh, int32_t ow, int32_t accumulate,
+                     void *stream);
+/* final 1x1 conv to one channel + ReLU on a post-ReLU input: d_o2[p,c] = (disp[p] > 0 ? g[p] : 0) * w[c] * (o2[p,c] > 0). */
+int edv_dot_channels_bwd(const float *g_dev, const float *disp_dev, const float *w_dev, const float *o2_dev, float *d_o2_dev, int64_t npix, int32_t C,
+                         void *stream);
+/* GroupNorm input gradient; stats = the forward's [F, groups, 2] (mean, rstd); sums = [F, groups, 2] scratch. */
+int edv_groupnorm_bwd(const float *x_dev, const float *stats_dev, const float *w_dev, const float *dy_dev, float *sums_dev, float *dx_dev, int32_t F,
+                      int32_t P, int32_t C, int32_t groups, int32_t accumulate, void *stream);
+/* temporal attention core, backward: dqkv [B*T*P, 3C] from qkv and dout [B*T*P, C]. */
+int edv_attn_temporal_bwd(const float *qkv_dev, const float *dout_dev, float *dqkv_dev, int32_t B, int32_t T, int32_t P, int32_t C, int32_t heads,
+                          void *stream);
+/* 3x3 convolution input gradient.  Stride 1: run edv_conv3x3 on dy with the weight repacked by edv_pack_conv3x3_bwd
+ * ([Cout,Cin,3,3] -> [Cin][3][3][Cout], taps flipped).  Stride 2: direct kernel on the forward's packed weight. */
+int edv_pack_conv3x3_bwd(const float *w_dev, float *wpacked_dev, int32_t Cout, int32_t Cin, void *stream);
+int edv_conv3x3_s2_bwd(const float *dy_dev, const float *wpacked_dev, float *dx_dev, int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                       void *stream);
+/* ConvTranspose(k = s) input gradient = edv_gemm of the pixel-unshuffled dy [F*h*w, s*s*C] with the transposed packed weight. */
+int edv_pixel_unshuffle(const float *dy_dev, float *A_dev, int32_t F, int32_t h, int32_t w, int32_t C, int32_t s, void *stream);
 
 #ifdef __cplusplus
 }

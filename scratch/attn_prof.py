@@ -8,5 +8,5 @@ qkv = torch.randn(F * N, 3 * heads * 64, device=dev); o = torch.empty(F * N, hea
 nb = lib.edv_attn_spatial_workspace(F, N, heads); ws = torch.empty(max(nb // 4, 4), device=dev)
 st = _lib.stream_ptr()
 for _ in range(50):
-    _lib.check(lib.edv_attn_spatial(qkv.data_ptr(), o.data_ptr(), F, N, heads, ws.data_ptr(), nb, st))
+    _lib.check(lib.edv_attn_spatial(qkv.data_ptr(), o.data_ptr(), F, N, heads, ws.data_ptr(), nb, None, st))
 torch.cuda.synchronize()

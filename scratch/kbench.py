@@ -54,7 +54,7 @@ def attn(F, N, heads):
     o = torch.empty(F * N, heads * 64, device=dev)
     nb = lib.edv_attn_spatial_workspace(F, N, heads)
     ws = torch.empty(max(nb // 4, 4), device=dev)
-    t = timeit(lambda: _lib.check(lib.edv_attn_spatial(qkv.data_ptr(), o.data_ptr(), F, N, heads, ws.data_ptr(), nb, st())))
+    t = timeit(lambda: _lib.check(lib.edv_attn_spatial(qkv.data_ptr(), o.data_ptr(), F, N, heads, ws.data_ptr(), nb, None, st())))
     print(f"attn F={F} N={N} heads={heads}: {t*1e6:8.1f} us  {4*N*N*64*heads*F/t/1e12:6.1f} TF", flush=True)
 
 

@@ -15,7 +15,7 @@ def attn(F, N, heads, reps=3):
     qkv = torch.randn(F * N, 3 * heads * 64, device=dev); o = torch.empty(F * N, heads * 64, device=dev)
     nb = lib.edv_attn_spatial_workspace(F, N, heads)
     ws = torch.empty(max(nb // 4, 4), device=dev)
-    for _ in range(reps): _lib.check(lib.edv_attn_spatial(qkv.data_ptr(), o.data_ptr(), F, N, heads, ws.data_ptr(), nb, st()))
+    for _ in range(reps): _lib.check(lib.edv_attn_spatial(qkv.data_ptr(), o.data_ptr(), F, N, heads, ws.data_ptr(), nb, None, st()))
     torch.cuda.synchronize()
 gemm(8192, 8192, 1024); gemm(10960, 1152, 384); gemm(10960, 1536, 4096)
 attn(8, 1370, 6); attn(8, 4096, 6)

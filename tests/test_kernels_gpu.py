@@ -249,7 +249,7 @@ def attn_spatial(lib, cuda, qd, o, Fr, N, heads):
     """edv_attn_spatial with the split workspace the planner asks for (poisoned, so a piece nobody wrote shows)."""
     nbytes = lib.edv_attn_spatial_workspace(Fr, N, heads)
     ws = torch.full((max(nbytes // 4, 4),), float("nan"), device=cuda)
-    _lib.check(lib.edv_attn_spatial(qd.data_ptr(), o.data_ptr(), Fr, N, heads, ws.data_ptr(), nbytes, st()), "edv_attn_spatial")
+    _lib.check(lib.edv_attn_spatial(qd.data_ptr(), o.data_ptr(), Fr, N, heads, ws.data_ptr(), nbytes, None, st()), "edv_attn_spatial")
     return nbytes
 
 
@@ -277,8 +277,8 @@ def test_attn_spatial_workspace_contract(lib, cuda):
     qd = torch.zeros(Fr * N, 3 * heads * 64, device=cuda)
     o = torch.empty(Fr * N, heads * 64, device=cuda)
     small = torch.empty(need // 4 - 4, device=cuda)
-    assert lib.edv_attn_spatial(qd.data_ptr(), o.data_ptr(), Fr, N, heads, None, 0, st()) != 0
-    assert lib.edv_attn_spatial(qd.data_ptr(), o.data_ptr(), Fr, N, heads, small.data_ptr(), need - 16, st()) != 0
+    assert lib.edv_attn_spatial(qd.data_ptr(), o.data_ptr(), Fr, N, heads, None, 0, None, st()) != 0
+    assert lib.edv_attn_spatial(qd.data_ptr(), o.data_ptr(), Fr, N, heads, small.data_ptr(), need - 16, None, st()) != 0
     assert "workspace" in lib.edv_last_error().decode()
 
 

@@ -4,6 +4,11 @@
 // q|k|v rows, rows = (frame, token).  Each kernel cites the forward it differentiates.
 #include "ops.hpp"
 
+// The bilinear adjoint must reproduce the forward's interpolation weights: ATen computes the source coordinate as a
+// ROUNDED float product and then subtracts its integer part; contraction would fuse the two (resample.hip has the same
+// pragma for the same reason).  Everything in this file is HBM-bound, so nothing is lost.
+#pragma clang fp contract(off)
+
 namespace edv {
 namespace {
 
@@ -78,12 +83,15 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float *__restr
 }
 
 // ---- elementwise ---------------------------------------------------------------------------------------------------------
-// out = (mode 1: d * gelu'(src) | mode 2: src > 0 ? d : 0 | mode 0: d) + (add ? add : 0)
+// out = (mode 1: d * gelu'(src) | mode 2: src > 0 ? d : 0 | mode 3: gelu(d) | mode 0: d) + (add ? add : 0)
 __global__ __launch_bounds__(256) void ew_bwd_kernel(const float *__restrict__ d, const float *__restrict__ src, const float *__restrict__ add,
                                                      float *__restrict__ out, long long n4, int mode) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long long)gridDim.x * 256) {
         f32x4 v = *reinterpret_cast<const f32x4 *>(d + 4 * i);
-        if (mode) {
+        if (mode == 3) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        } else if (mode) {
             const f32x4 sv = *reinterpret_cast<const f32x4 *>(src + 4 * i);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = mode == 1 ? v[e] * gelu_erf_grad(sv[e]) : (sv[e] > 0.f ? v[e] : 0.f);
@@ -197,32 +205,35 @@ __global__ __launch_bounds__(256) void tall_tn_reduce_kernel(const float *__rest
 }
 
 // LoRA factor gradients from dBp [out, r] (= s dY^T (X A'^T)) and dApT [in, r] (= s X^T (dY B')), mylora/layers.py:148-157, 384-393.
-//   lora:   dB = dBp,            dA[j, k] = dApT[k, j]
-//   dvlora: dB = dBp * V, dV = dBp * B;  dA = dApT^T * U, dU = dApT^T * A        (A' = A * U, B' = B * V elementwise)
+//   lora:   dB = dBp,  dA[j, k] = dApT[k, j]
+//   dvlora: A' = A * U with U [r, 1], B' = B * V with V [out, 1]:
+//           dB[n, j] = dBp[n, j] V[n],  dV[n] = sum_j dBp[n, j] B[n, j],  dA[j, k] = dApT[k, j] U[j],  dU[j] = sum_k dApT[k, j] A[j, k]
 __global__ __launch_bounds__(256) void lora_grad_finalize_kernel(const float *__restrict__ dBp, const float *__restrict__ dApT, const float *__restrict__ A,
                                                                  const float *__restrict__ Bm, const float *__restrict__ U, const float *__restrict__ V,
-                                                                 float *__restrict__ dA, float *__restrict__ dB, float *__restrict__ dU,
-                                                                 float *__restrict__ dV, int nout, int nin, int r) {
+                                                                 float *__restrict__ dA, float *__restrict__ dB, float *__restrict__ dV, int nout, int nin,
+                                                                 int r) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < nout * r) {
-        const float g = dBp[i];
-        if (V) {
-            if (dB) dB[i] = g * V[i];
-            if (dV) dV[i] = g * Bm[i];
-        } else if (dB) {
-            dB[i] = g;
-        }
+    if (i < nout * r && dB) dB[i] = dBp[i] * (V ? V[i / r] : 1.f);
+    if (i < nout && V && dV) {
+        float s = 0.f;
+        for (int j = 0; j < r; ++j) s += dBp[i * r + j] * Bm[i * r + j];
+        dV[i] = s;
     }
-    if (i < r * nin) {
+    if (i < r * nin && dA) {
         const int j = i / nin, k = i - j * nin;
-        const float g = dApT[k * r + j];
-        if (U) {
-            if (dA) dA[i] = g * U[i];
-            if (dU) dU[i] = g * A[i];
-        } else if (dA) {
-            dA[i] = g;
-        }
+        dA[i] = dApT[k * r + j] * (U ? U[j] : 1.f);
     }
+}
+// dU[j] = sum_k dApT[k, j] A[j, k]: one workgroup per j
+__global__ __launch_bounds__(256) void lora_grad_u_kernel(const float *__restrict__ dApT, const float *__restrict__ A, float *__restrict__ dU, int nin, int r) {
+    __shared__ float red[4];
+    const int j = blockIdx.x;
+    float s = 0.f;
+    for (int k = threadIdx.x; k < nin; k += 256) s += dApT[k * r + j] * A[(long long)j * nin + k];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) dU[j] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
 // ---- bilinear, align_corners=True, backward as a deterministic gather (resample.hip bilinear_*) ---------------------------
@@ -233,10 +244,12 @@ __device__ __forceinline__ void bl_src(int o, float ratio, int in, int out, int 
         lam = 0.f;
         return;
     }
-    const float s = __fmul_rn(ratio, (float)o);  // the forward's rounded product (resample.hip lin_coord)
+    // the forward's ROUNDED product (resample.hip lin_coord).  Both operations are written here, under this file's
+    // contract(off): the header's __fmul_rn / __fsub_rn bodies carry the contract flag and would fuse with each other.
+    const float s = ratio * (float)o;
     i0 = (int)s;
     i1 = i0 + (i0 < in - 1 ? 1 : 0);
-    lam = fminf(fmaxf(__fsub_rn(s, (float)i0), 0.f), 1.f);
+    lam = fminf(fmaxf(s - (float)i0, 0.f), 1.f);
 }
 // weight of output coordinate o on input coordinate i
 __device__ __forceinline__ float bl_weight(int o, int i, float ratio, int in, int out) {
@@ -510,15 +523,15 @@ __global__ __launch_bounds__(256) void pack_conv3x3_bwd_kernel(const float *__re
     out[i] = w[(((long long)co * Cin + ci) * 3 + (2 - ky)) * 3 + (2 - kx)];
 }
 
-// Aeff [r, nin] = A * U;  BgT [r, nout] = (B * V * gamma)^T   (U, V, gamma optional)
+// Aeff [r, nin] = A * U (U [r, 1]);  BgT [r, nout] = (B * V * gamma)^T (V, gamma [nout])   (U, V, gamma optional)
 __global__ __launch_bounds__(256) void lora_factors_kernel(const float *__restrict__ A, const float *__restrict__ Bm, const float *__restrict__ U,
                                                            const float *__restrict__ V, const float *__restrict__ gamma, float *__restrict__ Aeff,
                                                            float *__restrict__ BgT, int nout, int nin, int r) {
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < r * nin) Aeff[i] = A[i] * (U ? U[i] : 1.f);
+    if (i < r * nin) Aeff[i] = A[i] * (U ? U[i / nin] : 1.f);
     if (i < r * nout) {
         const int j = i / nout, n = i - j * nout;
-        BgT[i] = Bm[n * r + j] * (V ? V[n * r + j] : 1.f) * (gamma ? gamma[n] : 1.f);
+        BgT[i] = Bm[n * r + j] * (V ? V[n] : 1.f) * (gamma ? gamma[n] : 1.f);
     }
 }
 
@@ -539,7 +552,7 @@ int layernorm_bwd(const float *x, RowMap xmap, const float *w, const float *dy, 
 
 int ew_bwd(const float *d, const float *src, const float *add, float *out, long long n, int mode, hipStream_t st) {
     EDV_CHECK(d && out && n > 0 && n % 4 == 0, "shape");
-    EDV_CHECK(mode >= 0 && mode <= 2 && (mode == 0 || src), "mode");
+    EDV_CHECK(mode >= 0 && mode <= 3 && (mode == 0 || mode == 3 || src), "mode");
     hipLaunchKernelGGL(ew_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, st, d, src, add, out, n / 4, mode);
     EDV_LAUNCH_OK();
     return 0;
@@ -602,8 +615,12 @@ int lora_grad_finalize(const float *dBp, const float *dApT, const float *A, cons
     EDV_CHECK((U == nullptr) == (V == nullptr), "U and V come together");
     EDV_CHECK(!U || (A && Bm), "dvlora needs A and B");
     const int n = (nout > nin ? nout : nin) * r;
-    hipLaunchKernelGGL(lora_grad_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dBp, dApT, A, Bm, U, V, dA, dB, dU, dV, nout, nin, r);
+    hipLaunchKernelGGL(lora_grad_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dBp, dApT, A, Bm, U, V, dA, dB, dV, nout, nin, r);
     EDV_LAUNCH_OK();
+    if (U && dU) {
+        hipLaunchKernelGGL(lora_grad_u_kernel, dim3(r), dim3(256), 0, st, dApT, A, dU, nin, r);
+        EDV_LAUNCH_OK();
+    }
     return 0;
 }
 

@@ -61,6 +61,10 @@ struct edv_ctx {
     std::unordered_map<std::string, Buf> ws;      // activations, owned
     bool prepared = false;
     bool capture = false;
+    bool train = false;           // forward keeps the activations the backward needs (edv_set_train)
+    bool train_prepared = false;  // transposed / flipped weights of the input-gradient GEMMs are current
+    bool have_saved = false;      // a training forward has run since the last backward
+    std::unordered_map<std::string, Buf> grads;  // gradients of the trainable parameters, owned
     int launches = 0;
     size_t bytes = 0;
     // geometry of the last forward (for edv_stage_copy)
@@ -303,6 +307,7 @@ struct Run {
             EDV_TRY(fold_linear(tb + ".ff.net.2", cfg.temporal_lora != 0));
         }
         c->prepared = true;
+        c->train_prepared = false;  // the folded LoRA weights changed: their transposes are stale
         return 0;
     }
 
@@ -346,27 +351,40 @@ struct Run {
         const std::string tb = p + ".transformer_blocks.0";
         const long long M = (long long)F * P;
         float *gn, *h, *hn, *qkv3, *att, *ff1, *ff2, *stats;
+        // training keeps: the module input, the GroupNorm statistics, h before each of its three residual updates,
+        // both q|k|v and the GEGLU input (names tagged with the module index); inference reuses one set of buffers
+        const std::string tg = c->train ? "mm" + std::to_string(m) + "." : "mm.";
+        float *hs[4];  // h after proj_in, after attention 0, after attention 1, after the feed-forward
+        const float *xin = x;
         EDV_TRY(wsbuf("mm.gn", (size_t)M * C, &gn));
-        EDV_TRY(wsbuf("mm.h", (size_t)M * C, &h));
+        EDV_TRY(wsbuf(tg + "h", (size_t)M * C, &h));
+        hs[0] = hs[1] = hs[2] = hs[3] = h;
+        if (c->train) {
+            float *xc;
+            EDV_TRY(wsbuf(tg + "xin", (size_t)M * C, &xc));
+            EDV_TRY(copy_f32(x, xc, M * C, st));
+            xin = xc;
+            for (int k = 1; k < 4; ++k) EDV_TRY(wsbuf(tg + "h" + std::to_string(k), (size_t)M * C, &hs[k]));
+        }
         EDV_TRY(wsbuf("mm.hn", (size_t)M * C, &hn));
-        EDV_TRY(wsbuf("mm.qkv", (size_t)M * 3 * C, &qkv3));
         EDV_TRY(wsbuf("mm.att", (size_t)M * C, &att));
-        EDV_TRY(wsbuf("mm.ff1", (size_t)M * 8 * C, &ff1));
+        EDV_TRY(wsbuf(tg + "ff1", (size_t)M * 8 * C, &ff1));
         EDV_TRY(wsbuf("mm.ff2", (size_t)M * 4 * C, &ff2));
-        EDV_TRY(wsbuf("mm.stats", (size_t)F * 32 * 2, &stats));
+        EDV_TRY(wsbuf(tg + "stats", (size_t)F * 32 * 2, &stats));
         const float *w, *b;
         EDV_TRY(param(p + ".norm.weight", &w));
         EDV_TRY(param(p + ".norm.bias", &b));
-        EDV_TRY(groupnorm(x, w, b, gn, stats, F, P, C, 32, 1e-6f, st));
+        EDV_TRY(groupnorm(xin, w, b, gn, stats, F, P, C, 32, 1e-6f, st));
         c->launches += 2;
         EDV_TRY(param(p + ".proj_in.weight", &w));
         EDV_TRY(param(p + ".proj_in.bias", &b));
-        EDV_TRY(linear(gn, M, C, w, C, b, h));
+        EDV_TRY(linear(gn, M, C, w, C, b, hs[0]));
         for (int a = 0; a < 2; ++a) {
             const std::string ab = tb + ".attention_blocks." + std::to_string(a);
             const float *pe;
             EDV_TRY(param(ab + ".pos_encoder.pe", &pe));
-            EDV_TRY(ln(h, identity_map(), tb + ".norms." + std::to_string(a), hn, M, C, 1e-5f, pe, P, T));
+            EDV_TRY(wsbuf(c->train ? tg + "qkv" + std::to_string(a) : std::string("mm.qkv"), (size_t)M * 3 * C, &qkv3));
+            EDV_TRY(ln(hs[a], identity_map(), tb + ".norms." + std::to_string(a), hn, M, C, 1e-5f, pe, P, T));
             const float *wqkv;
             EDV_TRY(packedw(ab + ".qkv", &wqkv));
             EDV_TRY(linear(hn, M, C, wqkv, 3 * C, nullptr, qkv3));
@@ -377,9 +395,9 @@ struct Run {
             c->launches++;
             EDV_TRY(param(ab + ".to_out.0.weight", &w));
             EDV_TRY(param(ab + ".to_out.0.bias", &b));
-            EDV_TRY(linear(att, M, C, w, C, b, h, ACT_NONE, nullptr, h));
+            EDV_TRY(linear(att, M, C, w, C, b, hs[a + 1], ACT_NONE, nullptr, hs[a]));
         }
-        EDV_TRY(ln(h, identity_map(), tb + ".ff_norm", hn, M, C, 1e-5f));
+        EDV_TRY(ln(hs[2], identity_map(), tb + ".ff_norm", hn, M, C, 1e-5f));
         EDV_TRY(param(tb + ".ff.net.0.proj.weight", &w));
         EDV_TRY(param(tb + ".ff.net.0.proj.bias", &b));
         EDV_TRY(linear(hn, M, C, w, 8 * C, b, ff1));
@@ -387,10 +405,10 @@ struct Run {
         c->launches++;
         EDV_TRY(lin_w(tb + ".ff.net.2", &w));
         EDV_TRY(param(tb + ".ff.net.2.bias", &b));
-        EDV_TRY(linear(ff2, M, 4 * C, w, C, b, h, ACT_NONE, nullptr, h));
+        EDV_TRY(linear(ff2, M, 4 * C, w, C, b, hs[3], ACT_NONE, nullptr, hs[2]));
         EDV_TRY(param(p + ".proj_out.weight", &w));
         EDV_TRY(param(p + ".proj_out.bias", &b));
-        EDV_TRY(linear(h, M, C, w, C, b, x, ACT_NONE, nullptr, x));
+        EDV_TRY(linear(hs[3], M, C, w, C, b, x, ACT_NONE, nullptr, x));
         return 0;
     }
 
@@ -401,29 +419,36 @@ struct Run {
     int fusion(int j, const float *x, const float *skip, int h, int w, int oh, int ow, float *out) {
         const std::string p = "head.scratch.refinenet" + std::to_string(j);
         const size_t n = (size_t)F * h * w * Fe;
-        float *t1, *t2, *s;
+        float *t1, *t2, *s, *t1a, *t1b;
+        // training keeps both conv1 outputs and the sum s (ReLU masks of the backward), tagged with the block index
+        const std::string tg = c->train ? "fu" + std::to_string(j) + "." : "fu.";
         EDV_TRY(wsbuf("fu.t1", n, &t1));
         EDV_TRY(wsbuf("fu.t2", n, &t2));
+        t1a = t1b = t1;
+        if (c->train) {
+            EDV_TRY(wsbuf(tg + "t1a", n, &t1a));
+            EDV_TRY(wsbuf(tg + "t1b", n, &t1b));
+        }
         const float *w1, *b1, *w2, *b2;
         const float *cur = x;
         if (skip) {
-            EDV_TRY(wsbuf("fu.s", n, &s));
+            EDV_TRY(wsbuf(tg + "s", n, &s));
             EDV_TRY(packedw(p + ".resConfUnit1.conv1.weight", &w1));
             EDV_TRY(param(p + ".resConfUnit1.conv1.bias", &b1));
             EDV_TRY(packedw(p + ".resConfUnit1.conv2.weight", &w2));
             EDV_TRY(param(p + ".resConfUnit1.conv2.bias", &b2));
-            EDV_TRY(conv3(skip, h, w, Fe, w1, b1, Fe, 1, t1, true));
+            EDV_TRY(conv3(skip, h, w, Fe, w1, b1, Fe, 1, t1a, true));
             // s = x + rcu1(skip) = x + skip + conv2(relu(t1)): both adds ride the conv2 epilogue
             // (skip_add at util/blocks.py:90 and :146)
-            EDV_TRY(conv3(t1, h, w, Fe, w2, b2, Fe, 1, s, true, ACT_NONE, skip, x));
+            EDV_TRY(conv3(t1a, h, w, Fe, w2, b2, Fe, 1, s, true, ACT_NONE, skip, x));
             cur = s;
         }
         EDV_TRY(packedw(p + ".resConfUnit2.conv1.weight", &w1));
         EDV_TRY(param(p + ".resConfUnit2.conv1.bias", &b1));
         EDV_TRY(packedw(p + ".resConfUnit2.conv2.weight", &w2));
         EDV_TRY(param(p + ".resConfUnit2.conv2.bias", &b2));
-        EDV_TRY(conv3(cur, h, w, Fe, w1, b1, Fe, 1, t1, true));
-        EDV_TRY(conv3(t1, h, w, Fe, w2, b2, Fe, 1, t2, true, ACT_NONE, cur, nullptr));
+        EDV_TRY(conv3(cur, h, w, Fe, w1, b1, Fe, 1, t1b, true));
+        EDV_TRY(conv3(t1b, h, w, Fe, w2, b2, Fe, 1, t2, true, ACT_NONE, cur, nullptr));
         const float *wo, *bo;
         EDV_TRY(param(p + ".out_conv.weight", &wo));
         EDV_TRY(param(p + ".out_conv.bias", &bo));
@@ -505,6 +530,7 @@ struct Run {
         }
         const float *pos = eb.pos;
         rb_suffix = "." + std::to_string(f0);
+        if (c->train) EDV_TRY(wsbuf("t.x.0", (size_t)MT * D, &xt));  // block i reads t.x.i and writes t.xmid.i, t.x.(i+1)
         EDV_TRY(patchify(x + (size_t)f0 * 3 * H * W, cols, F, H, W, cfg.image_h, cfg.image_w, st));
         c->launches++;
         {
@@ -531,27 +557,49 @@ struct Run {
         for (int i = 0; i < depth; ++i) {
             const std::string bp = "pretrained.blocks." + std::to_string(i);
             const float *w, *b, *gam;
-            EDV_TRY(ln(xt, identity_map(), bp + ".norm1", xn, MT, D, 1e-6f));
+            // inference: one residual stream updated in place; training: every block keeps its input, its mid-point,
+            // its normed MLP input, q|k|v, the attention output + log-sum-exp and the fc1 pre-activation
+            float *x_in = xt, *x_mid = xt, *x_out = xt, *xn2 = xn, *lse = nullptr, *pre = nullptr;
+            if (c->train) {
+                const std::string is = "." + std::to_string(i);
+                x_in = xt;
+                EDV_TRY(wsbuf("t.xmid" + is, (size_t)MT * D, &x_mid));
+                EDV_TRY(wsbuf("t.x." + std::to_string(i + 1), (size_t)MT * D, &x_out));
+                EDV_TRY(wsbuf("t.xn2" + is, (size_t)MT * D, &xn2));
+                EDV_TRY(wsbuf("t.qkv" + is, (size_t)MT * 3 * D, &qkv));
+                EDV_TRY(wsbuf("t.att" + is, (size_t)MT * D, &att));
+                EDV_TRY(wsbuf("t.lse" + is, (size_t)F * heads * ntok, &lse));
+                EDV_TRY(wsbuf("t.pre" + is, (size_t)MT * 4 * D, &pre));
+                EDV_TRY(wsbuf("t.hid" + is, (size_t)MT * 4 * D, &hid));
+            }
+            EDV_TRY(ln(x_in, identity_map(), bp + ".norm1", xn, MT, D, 1e-6f));
             EDV_TRY(param(bp + ".attn.qkv.weight", &w));
             EDV_TRY(param(bp + ".attn.qkv.bias", &b));
             EDV_TRY(linear(xn, MT, D, w, 3 * D, b, qkv));
             {
                 Bracket b_(c, KC_ATTN_SPATIAL, st);
-                EDV_TRY(attn_spatial(qkv, att, F, ntok, heads, eb.attws + (size_t)lane * eb.attws_each, eb.attws_each, st));
+                EDV_TRY(attn_spatial(qkv, att, F, ntok, heads, eb.attws + (size_t)lane * eb.attws_each, eb.attws_each, st, lse));
             }
             c->launches++;
             EDV_TRY(param(bp + ".attn.proj.weight", &w));
             EDV_TRY(param(bp + ".attn.proj.bias", &b));
             EDV_TRY(param(bp + ".ls1.gamma", &gam));
-            EDV_TRY(linear(att, MT, D, w, D, b, xt, ACT_NONE, gam, xt));
-            EDV_TRY(ln(xt, identity_map(), bp + ".norm2", xn, MT, D, 1e-6f));
+            EDV_TRY(linear(att, MT, D, w, D, b, x_mid, ACT_NONE, gam, x_in));
+            EDV_TRY(ln(x_mid, identity_map(), bp + ".norm2", xn2, MT, D, 1e-6f));
             EDV_TRY(lin_w(bp + ".mlp.fc1", &w));
             EDV_TRY(param(bp + ".mlp.fc1.bias", &b));
-            EDV_TRY(linear(xn, MT, D, w, 4 * D, b, hid, ACT_GELU));
+            if (pre) {  // same values as the fused epilogue: GELU of the stored fp32 pre-activation
+                EDV_TRY(linear(xn2, MT, D, w, 4 * D, b, pre, ACT_NONE));
+                EDV_TRY(ew_bwd(pre, nullptr, nullptr, hid, MT * 4 * D, 3, st));
+                c->launches++;
+            } else {
+                EDV_TRY(linear(xn2, MT, D, w, 4 * D, b, hid, ACT_GELU));
+            }
             EDV_TRY(lin_w(bp + ".mlp.fc2", &w));
             EDV_TRY(param(bp + ".mlp.fc2.bias", &b));
             EDV_TRY(param(bp + ".ls2.gamma", &gam));
-            EDV_TRY(linear(hid, MT, 4 * D, w, D, b, xt, ACT_NONE, gam, xt));
+            EDV_TRY(linear(hid, MT, 4 * D, w, D, b, x_out, ACT_NONE, gam, x_mid));
+            xt = x_out;
             if (cfg.residual_mask & (1u << i)) EDV_TRY(res_bottleneck(i, xt));
             if (i == 0) EDV_TRY(snapshot("block0", xt, (size_t)MT * D));
             if (tapj < 4 && i == cfg.taps[tapj]) {
@@ -804,6 +852,346 @@ struct Run {
         }
         return 0;
     }
+
+    // =========================================================================================
+    // Backward.  Trainable: the LoRA / DV-LoRA factors of mlp.fc1 / mlp.fc2 in every encoder
+    // block (endodav/layers.py:5-34 names lora_A, lora_B, lora_U, lora_V); everything else is frozen, so each operator
+    // contributes its input gradient only.  Mirrors forward() in reverse on the activations a training forward kept.
+    int gradbuf(const std::string &name, size_t n, float **out) { return alloc_buf(c, c->grads, name, n, st, out); }
+    int saved(const std::string &name, const float **out) {
+        auto it = c->ws.find(name);
+        EDV_CHECK(it != c->ws.end() && it->second.p, "activation not saved (run a forward with edv_set_train first): " + name);
+        *out = it->second.p;
+        return 0;
+    }
+    // transposed (NT-form) weight of dX = (dY * gamma) W, cached under "T." + key
+    int make_t(const std::string &key, const float *W, int ldw, int N, int K, const float *gamma) {
+        float *wt;
+        EDV_TRY(pk("T." + key, (size_t)N * K, &wt));
+        return transpose_scale(W, ldw, gamma, wt, N, K, st);
+    }
+    int make_t_lin(const std::string &p, const float *gamma = nullptr) {
+        const float *W;
+        EDV_TRY(lin_w(p, &W));
+        const Param &q = c->params[p + ".weight"];
+        EDV_CHECK(q.shape.size() >= 2, "rank of " + p);
+        long long in = 1;
+        for (size_t k = 1; k < q.shape.size(); ++k) in *= q.shape[k];
+        return make_t(p, W, (int)in, (int)q.shape[0], (int)in, gamma);
+    }
+    int make_b_c3(const std::string &p) {  // flipped, in/out-swapped packed weight of the stride-1 input-gradient convolution
+        const float *w;
+        EDV_TRY(param(p + ".weight", &w, 4));
+        const Param &q = c->params[p + ".weight"];
+        float *out;
+        EDV_TRY(pk("B." + p, (size_t)q.numel(), &out));
+        return pack_conv3x3_bwd(w, out, (int)q.shape[0], (int)q.shape[1], st);
+    }
+    int prepare_train() {
+        EDV_CHECK(c->prepared, "edv_prepare has not run");
+        EDV_CHECK(!cfg.conv_head && !cfg.use_clstoken && !cfg.residual_mask && !cfg.temporal_lora && !cfg.out_sigmoid,
+                  "training supports the VDA head without use_clstoken / residual blocks / temporal_lora / out_sigmoid");
+        EDV_CHECK(cfg.lora_type == EDV_LORA_NONE || cfg.lora_type == EDV_LORA_LORA || cfg.lora_type == EDV_LORA_DVLORA,
+                  "training supports lora_type none, lora and dvlora");
+        const int *oc = cfg.out_channels;
+        for (int i = 0; i < depth; ++i) {
+            const std::string bp = "pretrained.blocks." + std::to_string(i);
+            const float *g1, *g2;
+            EDV_TRY(param(bp + ".ls1.gamma", &g1));
+            EDV_TRY(param(bp + ".ls2.gamma", &g2));
+            EDV_TRY(make_t_lin(bp + ".attn.qkv"));
+            EDV_TRY(make_t_lin(bp + ".attn.proj", g1));
+            EDV_TRY(make_t_lin(bp + ".mlp.fc1"));
+            EDV_TRY(make_t_lin(bp + ".mlp.fc2", g2));
+        }
+        for (int j = 0; j < 4; ++j) EDV_TRY(make_t_lin("head.projects." + std::to_string(j)));
+        for (int j = 0; j < 2; ++j) {
+            const std::string rp = "head.resize_layers." + std::to_string(j);
+            const int s2 = (j == 0 ? 16 : 4);
+            const float *wp;
+            EDV_TRY(packedw(rp + ".weight", &wp));
+            EDV_TRY(make_t(rp, wp, oc[j], s2 * oc[j], oc[j], nullptr));
+        }
+        for (int j = 1; j <= 4; ++j) EDV_TRY(make_b_c3("head.scratch.layer" + std::to_string(j) + "_rn"));
+        for (int j = 1; j <= 4; ++j) {
+            const std::string p = "head.scratch.refinenet" + std::to_string(j);
+            for (int u = 1; u <= 2; ++u) {
+                if (j == 4 && u == 1) continue;
+                EDV_TRY(make_b_c3(p + ".resConfUnit" + std::to_string(u) + ".conv1"));
+                EDV_TRY(make_b_c3(p + ".resConfUnit" + std::to_string(u) + ".conv2"));
+            }
+            EDV_TRY(make_t_lin(p + ".out_conv"));
+        }
+        EDV_TRY(make_b_c3("head.scratch.output_conv1"));
+        EDV_TRY(make_b_c3("head.scratch.output_conv2.0"));
+        const int mmC[4] = {oc[2], oc[3], Fe, Fe};
+        for (int m = 0; m < 4; ++m) {
+            const std::string p = "head.motion_modules." + std::to_string(m) + ".temporal_transformer";
+            const std::string tb = p + ".transformer_blocks.0";
+            const int C = mmC[m];
+            EDV_TRY(make_t_lin(p + ".proj_in"));
+            EDV_TRY(make_t_lin(p + ".proj_out"));
+            for (int a = 0; a < 2; ++a) {
+                const std::string ab = tb + ".attention_blocks." + std::to_string(a);
+                const float *wq;
+                EDV_TRY(packedw(ab + ".qkv", &wq));
+                EDV_TRY(make_t(ab + ".qkv", wq, C, 3 * C, C, nullptr));
+                EDV_TRY(make_t_lin(ab + ".to_out.0"));
+            }
+            EDV_TRY(make_t_lin(tb + ".ff.net.0.proj"));
+            EDV_TRY(make_t_lin(tb + ".ff.net.2"));
+        }
+        c->train_prepared = true;
+        return 0;
+    }
+    // dX[M, K] = dY[M, N] W  through the NT GEMM with the cached transposed weight ("T." + key is [K, N])
+    int dgemm(const float *dY, long long M, int N, const std::string &key, int K, float *dX, const float *R1 = nullptr) {
+        const float *wt;
+        EDV_TRY(packedw("T." + key, &wt));
+        return linear(dY, M, N, wt, K, nullptr, dX, ACT_NONE, nullptr, R1);
+    }
+    int dconv3(const float *dY, int H, int W, int Cout_fwd, const std::string &p, int Cin_fwd, float *dX) {
+        const float *wb;
+        EDV_TRY(packedw("B." + p, &wb));
+        return conv3(dY, H, W, Cout_fwd, wb, nullptr, Cin_fwd, 1, dX, false);
+    }
+
+    // motion module backward, in place on d [F, P, C] (dL/d output -> dL/d input)
+    int motion_module_bwd(int m, float *d, int P, int C) {
+        const std::string p = "head.motion_modules." + std::to_string(m) + ".temporal_transformer";
+        const std::string tb = p + ".transformer_blocks.0";
+        const std::string tg = "mm" + std::to_string(m) + ".";
+        const long long M = (long long)F * P;
+        float *dh, *t1, *t3, *t4, *t8, *sums;
+        EDV_TRY(wsbuf("g.mm.dh", (size_t)M * C, &dh));
+        EDV_TRY(wsbuf("g.mm.t1", (size_t)M * C, &t1));
+        EDV_TRY(wsbuf("g.mm.t3", (size_t)M * 3 * C, &t3));
+        EDV_TRY(wsbuf("g.mm.t4", (size_t)M * 4 * C, &t4));
+        EDV_TRY(wsbuf("g.mm.t8", (size_t)M * 8 * C, &t8));
+        EDV_TRY(wsbuf("g.mm.sums", (size_t)F * 32 * 2, &sums));
+        const float *xin, *stats, *hsv[3], *qkvs[2], *ff1, *w;
+        EDV_TRY(saved(tg + "xin", &xin));
+        EDV_TRY(saved(tg + "stats", &stats));
+        EDV_TRY(saved(tg + "h", &hsv[0]));
+        EDV_TRY(saved(tg + "h1", &hsv[1]));
+        EDV_TRY(saved(tg + "h2", &hsv[2]));
+        EDV_TRY(saved(tg + "qkv0", &qkvs[0]));
+        EDV_TRY(saved(tg + "qkv1", &qkvs[1]));
+        EDV_TRY(saved(tg + "ff1", &ff1));
+        EDV_TRY(dgemm(d, M, C, p + ".proj_out", C, dh));                   // x = xin + proj_out(h3)
+        EDV_TRY(dgemm(dh, M, C, tb + ".ff.net.2", 4 * C, t4));             // h3 = h2 + ff2 W2
+        EDV_TRY(geglu_bwd(ff1, t4, t8, M, 4 * C, st));
+        EDV_TRY(dgemm(t8, M, 8 * C, tb + ".ff.net.0.proj", C, t1));
+        EDV_TRY(param(tb + ".ff_norm.weight", &w));
+        EDV_TRY(layernorm_bwd(hsv[2], identity_map(), w, t1, identity_map(), dh, identity_map(), M, C, 1e-5f, true, st));
+        for (int a = 1; a >= 0; --a) {
+            const std::string ab = tb + ".attention_blocks." + std::to_string(a);
+            EDV_TRY(dgemm(dh, M, C, ab + ".to_out.0", C, t1));             // h(a+1) = h(a) + to_out(att)
+            EDV_TRY(attn_temporal_bwd(qkvs[a], t1, t3, B, T, P, C, 8, st));
+            EDV_TRY(dgemm(t3, M, 3 * C, ab + ".qkv", C, t1));
+            EDV_TRY(param(tb + ".norms." + std::to_string(a) + ".weight", &w));
+            EDV_TRY(layernorm_bwd(hsv[a], identity_map(), w, t1, identity_map(), dh, identity_map(), M, C, 1e-5f, true, st));
+        }
+        EDV_TRY(dgemm(dh, M, C, p + ".proj_in", C, t1));
+        EDV_TRY(param(p + ".norm.weight", &w));
+        EDV_TRY(groupnorm_bwd(xin, stats, w, t1, sums, d, F, P, C, 32, true, st));
+        c->launches += 8;
+        return 0;
+    }
+
+    // FeatureFusionBlock backward: d_out [F,oh,ow,Fe] -> d_x (and d_skip when the block has a skip input), both [F,h,w,Fe]
+    int fusion_bwd(int j, const float *d_out, const float *cur_or_x, const float *skip, int h, int w, int oh, int ow, float *d_x, float *d_skip) {
+        const std::string p = "head.scratch.refinenet" + std::to_string(j);
+        const std::string tg = "fu" + std::to_string(j) + ".";
+        const size_t n = (size_t)F * h * w * Fe;
+        const long long MP_ = (long long)F * h * w;
+        float *a, *b2;
+        EDV_TRY(wsbuf("g.fu.a", n, &a));
+        EDV_TRY(wsbuf("g.fu.b", n, &b2));
+        const float *t1a = nullptr, *t1b, *cur = cur_or_x;
+        EDV_TRY(saved(tg + "t1b", &t1b));
+        if (skip) {
+            EDV_TRY(saved(tg + "t1a", &t1a));
+            EDV_TRY(saved(tg + "s", &cur));
+        }
+        EDV_TRY(bilinear_bwd(d_out, a, F, h, w, Fe, oh, ow, false, st));                      // out = up(out_conv(t2))
+        EDV_TRY(dgemm(a, MP_, Fe, p + ".out_conv", Fe, d_x));                                  // d_x <- d_t2 for now
+        EDV_TRY(dconv3(d_x, h, w, Fe, p + ".resConfUnit2.conv2", Fe, a));                      // t2 = cur + conv2(relu(t1b))
+        EDV_TRY(ew_bwd(a, t1b, nullptr, a, (long long)n, 2, st));
+        EDV_TRY(dconv3(a, h, w, Fe, p + ".resConfUnit2.conv1", Fe, b2));                       // t1b = conv1(relu(cur))
+        EDV_TRY(ew_bwd(b2, cur, d_x, d_x, (long long)n, 2, st));                               // d_cur = d_t2 + mask(cur) * .
+        if (skip) {                                                                            // cur = x + skip + conv2a(relu(t1a))
+            EDV_TRY(dconv3(d_x, h, w, Fe, p + ".resConfUnit1.conv2", Fe, a));
+            EDV_TRY(ew_bwd(a, t1a, nullptr, a, (long long)n, 2, st));
+            EDV_TRY(dconv3(a, h, w, Fe, p + ".resConfUnit1.conv1", Fe, b2));                   // t1a = conv1a(relu(skip))
+            EDV_TRY(ew_bwd(b2, skip, d_x, d_skip, (long long)n, 2, st));
+        }
+        c->launches += 6;
+        return 0;
+    }
+
+    int backward(const float *disp0, const float *const g[4]) {
+        EDV_CHECK(c->train && c->have_saved, "edv_backward needs a forward run under edv_set_train(1)");
+        if (!c->train_prepared) EDV_TRY(prepare_train());
+        B = c->F / c->T; T = c->T; F = c->F; ph = c->ph; pw = c->pw; P0 = ph * pw;
+        c0 = cfg.include_cls_token ? 1 : 0;
+        ntok = c->ntok;
+        const long long MT = (long long)F * ntok, MP = (long long)F * P0;
+        const int *oc = cfg.out_channels;
+        const int h1 = 4 * ph, w1 = 4 * pw, h2 = 2 * ph, w2 = 2 * pw, h3 = ph, w3 = pw, h4 = (ph - 1) / 2 + 1, w4 = (pw - 1) / 2 + 1;
+        const int h0 = 8 * ph, w0 = 8 * pw, ih = cfg.image_h, iw = cfg.image_w, Fh = Fe / 2;
+        skws = nullptr;
+        skws_floats = 0;
+
+        // ---------------- output head: disp[k] = down(disp[k-1]); disp[0] = relu(dot(relu(conv2(up(conv1(p1)))))) ----
+        int sh[4], sw[4];
+        sh[0] = ih; sw[0] = iw;
+        for (int k = 1; k < 4; ++k) { sh[k] = sh[k - 1] / 2; sw[k] = sw[k - 1] / 2; }
+        float *gd[3];
+        for (int k = 2; k >= 0; --k) {
+            EDV_TRY(wsbuf("g.d" + std::to_string(k), (size_t)F * sh[k] * sw[k], &gd[k]));
+            EDV_TRY(copy_f32(g[k], gd[k], (long long)F * sh[k] * sw[k], st));
+            EDV_TRY(bilinear_bwd(k == 2 ? g[3] : gd[k + 1], gd[k], F, sh[k], sw[k], 1, sh[k + 1], sw[k + 1], true, st));
+        }
+        float *d_o2, *d_up, *d_o1, *d_p1;
+        const float *o2, *w;
+        EDV_TRY(saved("hd.o2", &o2));
+        EDV_TRY(wsbuf("g.o2", (size_t)F * ih * iw * 32, &d_o2));
+        EDV_TRY(wsbuf("g.up", (size_t)F * ih * iw * Fh, &d_up));
+        EDV_TRY(wsbuf("g.o1", (size_t)F * h0 * w0 * Fh, &d_o1));
+        EDV_TRY(wsbuf("g.p1", (size_t)F * h0 * w0 * Fe, &d_p1));
+        EDV_TRY(param("head.scratch.output_conv2.2.weight", &w));
+        EDV_TRY(dot_channels_bwd(gd[0], disp0, w, o2, d_o2, (long long)F * ih * iw, 32, st));
+        EDV_TRY(dconv3(d_o2, ih, iw, 32, "head.scratch.output_conv2.0", Fh, d_up));
+        EDV_TRY(bilinear_bwd(d_up, d_o1, F, h0, w0, Fh, ih, iw, false, st));
+        EDV_TRY(dconv3(d_o1, h0, w0, Fh, "head.scratch.output_conv1", Fe, d_p1));
+
+        // ---------------- fusion blocks and the two motion modules between them ----------------
+        float *d_p2, *d_p3, *d_p4, *d_r[5];
+        EDV_TRY(wsbuf("g.p2", (size_t)F * h1 * w1 * Fe, &d_p2));
+        EDV_TRY(wsbuf("g.p3", (size_t)F * h2 * w2 * Fe, &d_p3));
+        EDV_TRY(wsbuf("g.p4", (size_t)F * h3 * w3 * Fe, &d_p4));
+        EDV_TRY(wsbuf("g.r1", (size_t)F * h1 * w1 * Fe, &d_r[1]));
+        EDV_TRY(wsbuf("g.r2", (size_t)F * h2 * w2 * Fe, &d_r[2]));
+        EDV_TRY(wsbuf("g.r3", (size_t)F * h3 * w3 * Fe, &d_r[3]));
+        EDV_TRY(wsbuf("g.r4", (size_t)F * h4 * w4 * Fe, &d_r[4]));
+        const float *r[5];
+        for (int j = 1; j <= 4; ++j) EDV_TRY(saved("r" + std::to_string(j), &r[j]));
+        EDV_TRY(fusion_bwd(1, d_p1, nullptr, r[1], h1, w1, h0, w0, d_p2, d_r[1]));
+        EDV_TRY(fusion_bwd(2, d_p2, nullptr, r[2], h2, w2, h1, w1, d_p3, d_r[2]));
+        EDV_TRY(motion_module_bwd(3, d_p3, h2 * w2, Fe));
+        EDV_TRY(fusion_bwd(3, d_p3, nullptr, r[3], h3, w3, h2, w2, d_p4, d_r[3]));
+        EDV_TRY(motion_module_bwd(2, d_p4, h3 * w3, Fe));
+        EDV_TRY(fusion_bwd(4, d_p4, r[4], nullptr, h4, w4, h3, w3, d_r[4], nullptr));
+
+        // ---------------- layerN_rn, motion modules 0/1, reassemble, projects -> gradient of the four taps ----------
+        float *d_l[5], *d_pj, *d_tap[4];
+        const int hs_[5] = {0, h1, h2, h3, h4}, ws_[5] = {0, w1, w2, w3, w4};
+        for (int j = 1; j <= 4; ++j) {
+            EDV_TRY(wsbuf("g.l" + std::to_string(j), (size_t)F * hs_[j] * ws_[j] * oc[j - 1], &d_l[j]));
+            EDV_TRY(dconv3(d_r[j], hs_[j], ws_[j], Fe, "head.scratch.layer" + std::to_string(j) + "_rn", oc[j - 1], d_l[j]));
+        }
+        EDV_TRY(motion_module_bwd(0, d_l[3], h3 * w3, oc[2]));
+        EDV_TRY(motion_module_bwd(1, d_l[4], h4 * w4, oc[3]));
+        {
+            int mx = oc[0];
+            for (int j = 1; j < 4; ++j) mx = oc[j] > mx ? oc[j] : mx;
+            EDV_TRY(wsbuf("g.pj", (size_t)MP * mx, &d_pj));
+        }
+        for (int j = 0; j < 4; ++j) {
+            EDV_TRY(wsbuf("g.tap" + std::to_string(j), (size_t)MP * D, &d_tap[j]));
+            const float *src = d_pj;
+            if (j < 2) {
+                const int s = j == 0 ? 4 : 2;
+                float *A;
+                EDV_TRY(wsbuf("g.unsh", (size_t)MP * s * s * oc[j], &A));
+                EDV_TRY(pixel_unshuffle(d_l[j + 1], A, F, ph, pw, oc[j], s, st));
+                EDV_TRY(dgemm(A, MP, s * s * oc[j], "head.resize_layers." + std::to_string(j), oc[j], d_pj));
+            } else if (j == 2) {
+                src = d_l[3];
+            } else {
+                const float *wc;
+                EDV_TRY(packedw("head.resize_layers.3.weight", &wc));
+                EDV_TRY(conv3x3_s2_bwd(d_l[4], wc, d_pj, F, ph, pw, oc[3], oc[3], st));
+            }
+            EDV_TRY(dgemm(src, MP, oc[j], "head.projects." + std::to_string(j), D, d_tap[j]));
+        }
+        c->launches += 12;
+
+        // ---------------- encoder ----------------
+        float *dxt, *t1, *t3, *t4, *delta, *lws;
+        EDV_TRY(wsbuf("g.xt", (size_t)MT * D, &dxt));
+        EDV_TRY(wsbuf("g.e1", (size_t)MT * D, &t1));
+        EDV_TRY(wsbuf("g.e3", (size_t)MT * 3 * D, &t3));
+        EDV_TRY(wsbuf("g.e4", (size_t)MT * 4 * D, &t4));
+        EDV_TRY(wsbuf("g.delta", (size_t)F * heads * ntok, &delta));
+        const int rank = cfg.lora_rank;
+        const bool lora = cfg.lora_type != EDV_LORA_NONE;
+        const size_t lws_n = lora ? lora_grads_workspace(MT, D, 4 * D, rank) : 4;
+        EDV_TRY(wsbuf("g.lora", lws_n, &lws));
+        EDV_HIP(hipMemsetAsync(dxt, 0, (size_t)MT * D * sizeof(float), st));
+        const float lscale = cfg.lora_type == EDV_LORA_LORA ? 2.0f : 1.0f;  // lora_alpha / r (endodav.py:108-112)
+        const float *nw;
+        EDV_TRY(param("pretrained.norm.weight", &nw));
+        int tapj = 3;
+        for (int i = depth - 1; i >= 0; --i) {
+            const std::string bp = "pretrained.blocks." + std::to_string(i), is = "." + std::to_string(i);
+            const float *x_in, *x_mid, *x_out, *xn2, *qkv, *att, *lse, *pre, *hid, *w2;
+            EDV_TRY(saved("t.x." + std::to_string(i), &x_in));
+            EDV_TRY(saved("t.x." + std::to_string(i + 1), &x_out));
+            EDV_TRY(saved("t.xmid" + is, &x_mid));
+            EDV_TRY(saved("t.xn2" + is, &xn2));
+            EDV_TRY(saved("t.qkv" + is, &qkv));
+            EDV_TRY(saved("t.att" + is, &att));
+            EDV_TRY(saved("t.lse" + is, &lse));
+            EDV_TRY(saved("t.pre" + is, &pre));
+            EDV_TRY(saved("t.hid" + is, &hid));
+            if (tapj >= 0 && cfg.taps[tapj] == i) {  // tap = norm(x_out) on the patch rows (vision_transformer.py:317-321)
+                EDV_TRY(layernorm_bwd(x_out, RowMap{P0, ntok, c0}, nw, d_tap[tapj], identity_map(), dxt, RowMap{P0, ntok, c0}, MP, D, 1e-6f, true, st));
+                --tapj;
+            }
+            // x_out = x_mid + ls2 * fc2(gelu(fc1(norm2(x_mid))))
+            if (lora) EDV_TRY(lora_step(bp + ".mlp.fc2", hid, 4 * D, dxt, D, MT, rank, lscale, bp + ".ls2.gamma", lws, lws_n));
+            EDV_TRY(dgemm(dxt, MT, D, bp + ".mlp.fc2", 4 * D, t4));
+            EDV_TRY(ew_bwd(t4, pre, nullptr, t4, MT * 4 * D, 1, st));
+            if (lora) EDV_TRY(lora_step(bp + ".mlp.fc1", xn2, D, t4, 4 * D, MT, rank, lscale, "", lws, lws_n));
+            EDV_TRY(dgemm(t4, MT, 4 * D, bp + ".mlp.fc1", D, t1));
+            EDV_TRY(param(bp + ".norm2.weight", &w2));
+            EDV_TRY(layernorm_bwd(x_mid, identity_map(), w2, t1, identity_map(), dxt, identity_map(), MT, D, 1e-6f, true, st));
+            if (i == 0) break;  // nothing trainable below block 0's MLP
+            // x_mid = x_in + ls1 * proj(attn(qkv(norm1(x_in))))
+            EDV_TRY(dgemm(dxt, MT, D, bp + ".attn.proj", D, t1));
+            EDV_TRY(attn_spatial_bwd(qkv, att, t1, lse, delta, t3, F, ntok, heads, st));
+            EDV_TRY(dgemm(t3, MT, 3 * D, bp + ".attn.qkv", D, t1));
+            EDV_TRY(param(bp + ".norm1.weight", &w2));
+            EDV_TRY(layernorm_bwd(x_in, identity_map(), w2, t1, identity_map(), dxt, identity_map(), MT, D, 1e-6f, true, st));
+            c->launches += 6;
+        }
+        c->have_saved = false;
+        return 0;
+    }
+    // gradients of the LoRA factors of one linear into c->grads["<p>.lora_A"] ... (mylora/layers.py:148-157, 384-393)
+    int lora_step(const std::string &p, const float *X, int nin, const float *G, int nout, long long M, int r, float s, const std::string &gamma_name,
+                  float *lws, size_t lws_n) {
+        if (!has(p + ".lora_A")) return 0;
+        const float *A, *Bm, *U = nullptr, *V = nullptr, *gam = nullptr;
+        EDV_TRY(param(p + ".lora_A", &A));
+        EDV_TRY(param(p + ".lora_B", &Bm));
+        if (cfg.lora_type == EDV_LORA_DVLORA) {
+            EDV_TRY(param(p + ".lora_U", &U));
+            EDV_TRY(param(p + ".lora_V", &V));
+        }
+        if (!gamma_name.empty()) EDV_TRY(param(gamma_name, &gam));
+        float *dA, *dB, *dU = nullptr, *dV = nullptr;
+        EDV_TRY(gradbuf(p + ".lora_A", (size_t)r * nin, &dA));
+        EDV_TRY(gradbuf(p + ".lora_B", (size_t)r * nout, &dB));
+        if (U) {
+            EDV_TRY(gradbuf(p + ".lora_U", (size_t)r, &dU));
+            EDV_TRY(gradbuf(p + ".lora_V", (size_t)nout, &dV));
+        }
+        c->launches += 8;
+        return lora_grads(X, nin, G, nout, M, nin, nout, r, A, Bm, U, V, s, gam, lws, lws_n, dA, dB, dU, dV, st);
+    }
 };
 
 }  // namespace
@@ -843,6 +1231,8 @@ int edv_destroy(edv_ctx *ctx) {
     for (auto &kv : ctx->packed)
         if (kv.second.p) (void)hipFree(kv.second.p);
     for (auto &kv : ctx->ws)
+        if (kv.second.p) (void)hipFree(kv.second.p);
+    for (auto &kv : ctx->grads)
         if (kv.second.p) (void)hipFree(kv.second.p);
     for (int h = 0; h < 4; ++h) {
         if (ctx->sub[h]) (void)hipStreamDestroy(ctx->sub[h]);
@@ -889,8 +1279,50 @@ int edv_forward(edv_ctx *ctx, const float *x_dev, int32_t B, int32_t T, int32_t 
     EDV_CHECK(T <= ctx->cfg.num_frames, "T exceeds num_frames (temporal_max_len)");
     EDV_CHECK((long long)B * T <= 65535, "too many frames in one call");
     for (int k = 0; k < 4; ++k) EDV_CHECK(disp_dev[k], "null output");
+    if (ctx->train) {
+        const edv_config &c = ctx->cfg;
+        EDV_CHECK(!c.conv_head && !c.use_clstoken && !c.residual_mask && !c.temporal_lora && !c.out_sigmoid,
+                  "training supports the VDA head without use_clstoken / residual blocks / temporal_lora / out_sigmoid");
+        EDV_CHECK(c.lora_type == EDV_LORA_NONE || c.lora_type == EDV_LORA_LORA || c.lora_type == EDV_LORA_DVLORA,
+                  "training supports lora_type none, lora and dvlora");
+        EDV_CHECK(!ctx->capture, "stage capture and training are exclusive");
+    }
     Run r(ctx, (hipStream_t)stream);
-    return r.forward(x_dev, B, T, H, W, disp_dev);
+    if (ctx->train) ctx->enc_streams = 1;  // the saved activations are per block, not per stream
+    const int rc = r.forward(x_dev, B, T, H, W, disp_dev);
+    ctx->have_saved = rc == 0 && ctx->train;
+    return rc;
+}
+
+int edv_set_train(edv_ctx *ctx, int32_t on) {
+    EDV_CHECK(ctx, "null context");
+    ctx->train = on != 0;
+    if (!ctx->train) ctx->have_saved = false;
+    return 0;
+}
+
+int edv_backward(edv_ctx *ctx, const float *disp0_dev, const float *const grad_disp_dev[4], void *stream) {
+    EDV_CHECK(ctx && disp0_dev && grad_disp_dev, "null argument");
+    for (int k = 0; k < 4; ++k) EDV_CHECK(grad_disp_dev[k], "null gradient");
+    Run r(ctx, (hipStream_t)stream);
+    return r.backward(disp0_dev, grad_disp_dev);
+}
+
+int edv_grad_copy(edv_ctx *ctx, const char *name, float *dst_dev, int64_t numel, void *stream) {
+    EDV_CHECK(ctx && name && dst_dev, "null argument");
+    auto it = ctx->grads.find(name);
+    EDV_CHECK(it != ctx->grads.end() && it->second.p, std::string("no gradient for ") + name);
+    EDV_CHECK(numel > 0 && (size_t)numel <= it->second.cap, std::string("gradient size mismatch for ") + name);
+    return copy_f32(it->second.p, dst_dev, numel, (hipStream_t)stream);
+}
+
+int edv_grad(edv_ctx *ctx, const char *name, float **grad_dev, int64_t *numel) {
+    EDV_CHECK(ctx && name && grad_dev && numel, "null argument");
+    auto it = ctx->grads.find(name);
+    EDV_CHECK(it != ctx->grads.end() && it->second.p, std::string("no gradient for ") + name);
+    *grad_dev = it->second.p;
+    *numel = (int64_t)it->second.cap;
+    return 0;
 }
 
 int edv_output_shape(const edv_ctx *ctx, int32_t scale, int32_t *h, int32_t *w) {
@@ -910,6 +1342,13 @@ int edv_output_shape(const edv_ctx *ctx, int32_t scale, int32_t *h, int32_t *w) 
 
 int edv_stage_copy(edv_ctx *ctx, const char *name, float *dst_dev, size_t *n, void *stream) {
     EDV_CHECK(ctx && name && n, "bad argument");
+    if (std::string(name).rfind("ws:", 0) == 0) {  // any workspace buffer by name, whole capacity (gradient-stage parity tests)
+        auto w = ctx->ws.find(std::string(name).substr(3));
+        EDV_CHECK(w != ctx->ws.end() && w->second.p, std::string("no such workspace buffer: ") + name);
+        *n = w->second.cap;
+        if (dst_dev) return copy_f32(w->second.p, dst_dev, (long long)w->second.cap, (hipStream_t)stream);
+        return 0;
+    }
     auto it = ctx->stages.find(name);
     EDV_CHECK(it != ctx->stages.end(), std::string("stage not available (capture off or unknown): ") + name);
     *n = it->second.second;

@@ -339,6 +339,38 @@ class _NativeCtx:
 
 
 # ---------------------------------------------------------------------------------------------
+class _EdvFunction(torch.autograd.Function):
+    """One training step through libendodav_hip: ``edv_forward`` under ``edv_set_train`` keeps the activations,
+    ``edv_backward`` turns dL/d("disp", 0..3) into the gradients of the LoRA factors (trainer_end_to_end_video.py:731,
+    :427-431).  The factors are passed as inputs only so that autograd routes their gradients."""
+
+    @staticmethod
+    def forward(ctx, model, x, names, *params):
+        outs = model._run_native(x, train=True)
+        ctx.model, ctx.names, ctx.device = model, names, x.device
+        ctx.handle = model._last.handle
+        ctx.shapes = [tuple(o.shape) for o in outs]
+        ctx.param_shapes = [tuple(p.shape) for p in params]
+        ctx.save_for_backward(outs[0])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        (disp0,) = ctx.saved_tensors
+        lib = _lib.load()
+        with torch.cuda.device(ctx.device):
+            gs = [(g.detach().contiguous().float() if g is not None else torch.zeros(shp, device=ctx.device)) for g, shp in zip(gouts, ctx.shapes)]
+            ptrs = (C.c_void_p * 4)(*[g.data_ptr() for g in gs])
+            stream = C.c_void_p(_lib.stream_ptr(ctx.device))
+            _lib.check(lib.edv_backward(C.c_void_p(ctx.handle), disp0.data_ptr(), ptrs, stream), "edv_backward")
+            grads = []
+            for name, shp in zip(ctx.names, ctx.param_shapes):
+                g = torch.empty(shp, device=ctx.device, dtype=torch.float32)
+                _lib.check(lib.edv_grad_copy(C.c_void_p(ctx.handle), name.encode(), g.data_ptr(), g.numel(), stream), f"edv_grad_copy({name})")
+                grads.append(g)
+        return (None, None, None, *grads)
+
+
 class endodav(nn.Module):
     """Drop-in for ``models.endodav.endodav`` (constructor: endodav.py:53-73)."""
 
@@ -509,10 +541,11 @@ class endodav(nn.Module):
             raise ValueError(f"expected a clip [B, T, 3, H, W], got {tuple(x.shape)}")
         if not x.is_cuda:
             raise RuntimeError("endodav_amd runs on MI355X only: the clip must be a CUDA/ROCm tensor (there is no CPU fallback)")
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError(
-                "backward through libendodav_hip is not built yet (SURVEY.md §8f rank 3): call under torch.no_grad()"
-            )
+        train_names: List[str] = []
+        if torch.is_grad_enabled():
+            if x.requires_grad:
+                raise NotImplementedError("libendodav_hip does not produce the gradient of the input clip (nothing in the reference asks for it)")
+            train_names = self._trainable_names()
         B, T, _, H, W = x.shape
         assert self.image_shape[0] % PATCH == 0, f"Input image height {self.image_shape[0]} is not a multiple of patch height {PATCH}"
         assert self.image_shape[1] % PATCH == 0, f"Input image width {self.image_shape[1]} is not a multiple of patch width: {PATCH}"
@@ -521,15 +554,36 @@ class endodav(nn.Module):
         x = x.detach().contiguous().float()
         if self.lora_type == "dash":
             self._dash_step()
+        if train_names:
+            sd = self.state_dict(keep_vars=True)
+            outs = _EdvFunction.apply(self, x, tuple(train_names), *[sd[n] for n in train_names])
+        else:
+            outs = self._run_native(x, train=False)
+        return {("disp", s): outs[s] for s in range(4)}
+
+    def _run_native(self, x: torch.Tensor, train: bool):
+        B, T, _, H, W = x.shape
         with torch.cuda.device(x.device):
             ctx = self._ensure_ctx(x.device)
+            lib = _lib.load()
+            _lib.check(lib.edv_set_train(C.c_void_p(ctx), int(train)), "edv_set_train")
             outs = [torch.empty((B * T, 1, h, w), device=x.device, dtype=torch.float32) for (h, w) in self.output_shapes()]
             ptrs = (C.c_void_p * 4)(*[o.data_ptr() for o in outs])
-            _lib.check(
-                _lib.load().edv_forward(C.c_void_p(ctx), x.data_ptr(), B, T, H, W, ptrs, C.c_void_p(_lib.stream_ptr(x.device))),
-                "edv_forward",
-            )
-        return {("disp", s): outs[s] for s in range(4)}
+            _lib.check(lib.edv_forward(C.c_void_p(ctx), x.data_ptr(), B, T, H, W, ptrs, C.c_void_p(_lib.stream_ptr(x.device))), "edv_forward")
+        return outs
+
+    def _trainable_names(self) -> List[str]:
+        """state_dict names of the parameters that require grad, in state_dict order.  The HIP backward produces the
+        gradients of the LoRA factors of mlp.fc1 / mlp.fc2 (what ``mark_only_part_as_trainable`` leaves trainable for
+        lora / dvlora, endodav/layers.py:5-34); a trainable parameter outside that set is refused, not silently frozen."""
+        names = [n for n, p in self.state_dict(keep_vars=True).items() if p.requires_grad]
+        bad = [n for n in names if not (".mlp.fc" in n and n.rsplit(".", 1)[-1] in ("lora_A", "lora_B", "lora_U", "lora_V"))]
+        if bad:
+            raise NotImplementedError(f"libendodav_hip has no gradient for {bad[:4]}{' ...' if len(bad) > 4 else ''}: only the LoRA factors of the "
+                                      "encoder MLPs are trainable through the HIP backward (SURVEY.md §8f rank 3)")
+        if names and self.lora_type not in ("lora", "dvlora"):
+            raise NotImplementedError(f"the HIP backward supports lora_type 'lora' and 'dvlora', not {self.lora_type!r}")
+        return names
 
     # ---- debug taps for the per-stage parity tests --------------------------------------------
     def set_capture(self, on: bool) -> None:

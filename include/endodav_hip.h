@@ -196,7 +196,21 @@ int edv_resize_bicubic(const float *x_dev, float *y_dev, int32_t planes, int32_t
 int edv_fold_lora(const float *W_dev, const float *A_dev, const float *B_dev, const float *U_dev, const float *V_dev, float scale, float *out_dev,
                   int32_t nout, int32_t nin, int32_t r, void *stream);
 
-/* ---- backward (fine-tune step): input gradients of the frozen operators and the gradients of the
+/* ---- fine-tune step (trainer_end_to_end_video.py:731 forward, :427-431 backward/step) ----
+ * edv_set_train(ctx, 1): edv_forward keeps the activations the backward needs (per encoder block: both residual-stream
+ * values, the normed MLP input, q|k|v, the attention output and its log-sum-exp, the fc1 pre-activation; per motion module
+ * and fusion block: the inputs of their norms and ReLUs).  Supported: VDA head, lora_type none / lora / dvlora, no
+ * use_clstoken / residual blocks / temporal_lora / out_sigmoid; anything else is refused with an error.
+ * edv_backward(ctx, disp0, grads): disp0 = the ("disp", 0) map the forward wrote, grads[k] = dL/d("disp", k), k = 0..3
+ * (all four required, contiguous fp32).  Leaves the gradient of every LoRA factor of mlp.fc1 / mlp.fc2
+ * ("pretrained.blocks.<i>.mlp.fc<j>.lora_{A,B,U,V}", the trainable set of endodav/layers.py:5-34) in context-owned
+ * device memory, fetched with edv_grad(ctx, name, &ptr, &numel).  edv_prepare must run again after the optimizer step. */
+int edv_set_train(edv_ctx *ctx, int32_t on);
+int edv_backward(edv_ctx *ctx, const float *disp0_dev, const float *const grad_disp_dev[4], void *stream);
+int edv_grad(edv_ctx *ctx, const char *name, float **grad_dev, int64_t *numel);
+int edv_grad_copy(edv_ctx *ctx, const char *name, float *dst_dev, int64_t numel, void *stream); /* stream-ordered copy into caller memory */
+
+/* ---- backward kernels (input gradients of the frozen operators, gradients of the LoRA factors): input gradients of the frozen operators and the gradients of the
  * LoRA factors, the only trainable tensors (endodav/layers.py:5-34).  Same layouts as the forward kernels. ---- */
 /* LayerNorm (no affine gradient): dx (+)= dLN(x; w, eps)(dy);  rows x dim, dim % 4 == 0, dim <= 1024. */
 int edv_layernorm_bwd(const float *x_dev, const float *w_dev, const float *dy_dev, float *dx_dev, int64_t rows, int32_t dim, float eps,
@@ -208,7 +222,8 @@ int edv_geglu_bwd(const float *x_dev, const float *dy_dev, float *dx_dev, int64_
 /* Wt[k, n] = W[n, k] * gamma[n] (gamma may be NULL): the NT-form weight of dX = (dY * gamma) W. */
 int edv_transpose_scale(const float *W_dev, const float *gamma_dev, float *Wt_dev, int32_t N, int32_t K, void *stream);
 /* LoRA / DV-LoRA factor gradients of y = gamma * (x (W + s (B*V)(A*U))^T + b) from x [M, nin] and G = dL/dy [M, nout]
- * (mylora/layers.py:148-157, 384-393).  U/V NULL = plain LoRA; gamma may be NULL; any output may be NULL.  r in {1,2,4,8}. */
+ * (mylora/layers.py:148-157, 384-393): A [r, nin], B [nout, r], U [r, 1], V [nout, 1].  U/V NULL = plain LoRA; gamma may be
+ * NULL; any output may be NULL.  r in {1,2,4,8}. */
 size_t edv_lora_grads_workspace(int64_t M, int32_t nin, int32_t nout, int32_t r); /* bytes */
 int edv_lora_grads(const float *x_dev, const float *g_dev, int64_t M, int32_t nin, int32_t nout, int32_t r, const float *A_dev, const float *B_dev,
                    const float *U_dev, const float *V_dev, float s, const float *gamma_dev, float *workspace_dev, size_t workspace_bytes, float *dA_dev,

@@ -99,7 +99,7 @@ def test_transpose_scale_feeds_the_dx_gemm(lib, cuda):
                                                         (70, 256, 64, 2, True, False)])
 def test_lora_grads(lib, cuda, M, nin, nout, r, dv, use_gamma):
     x, G = rnd(M, nin, seed=1), rnd(M, nout, seed=2)
-    A, Bm, U, V = rnd(r, nin, seed=3), rnd(nout, r, seed=4), rnd(r, nin, seed=5) + 1.2, rnd(nout, r, seed=6) + 1.2
+    A, Bm, U, V = rnd(r, nin, seed=3), rnd(nout, r, seed=4), rnd(r, 1, seed=5) + 1.2, rnd(nout, 1, seed=6) + 1.2  # DVLinear: U [r,1], V [out,1]
     W, gamma, s = rnd(nout, nin, seed=7, scale=0.05), (rnd(nout, seed=8) + 1.5 if use_gamma else None), 0.75
 
     def fwd(a, b, u, v):
@@ -156,11 +156,34 @@ def test_attn_spatial_bwd(lib, cuda, Fr, N, heads):
 
 @pytest.mark.parametrize("Fr,ih,iw,Cc,oh,ow,acc", [(2, 37, 37, 64, 74, 74, False), (1, 148, 148, 32, 259, 259, False), (2, 74, 50, 1, 37, 25, True),
                                                    (1, 19, 19, 64, 37, 37, True), (3, 5, 7, 4, 5, 7, False), (1, 1, 1, 4, 3, 3, False),
-                                                   (1, 518, 518, 1, 259, 259, False)])
+                                                   (1, 518, 518, 1, 259, 259, False), (2, 128, 160, 32, 224, 280, False), (2, 224, 280, 1, 112, 140, True),
+                                                   (2, 56, 70, 1, 28, 35, True), (1, 64, 80, 64, 128, 160, False)])
 def test_bilinear_bwd(lib, cuda, Fr, ih, iw, Cc, oh, ow, acc):
+    """Adjoint of the forward the kernels actually compute: source coordinates in fp32 as ATen's forward (and CUDA
+    backward) derives them.  (ATen's CPU backward uses a double-precision scale, 1e-5 .. 5e-5 away at these sizes.)"""
+    import numpy as np
+
+    def interp_matrix(n_in, n_out):
+        Wm = np.zeros((n_out, n_in), dtype=np.float64)
+        ratio = np.float32(n_in - 1) / np.float32(n_out - 1) if n_out > 1 else np.float32(0)
+        for o in range(n_out):
+            if n_in == n_out:
+                Wm[o, o] = 1.0
+                continue
+            src = np.float32(ratio * np.float32(o))
+            i0 = int(src)
+            i1 = i0 + (1 if i0 < n_in - 1 else 0)
+            lam = float(np.float32(src - np.float32(i0)))
+            Wm[o, i0] += 1.0 - lam
+            Wm[o, i1] += lam
+        return torch.from_numpy(Wm)
+
     x, g = rnd(Fr, Cc, ih, iw, seed=1), rnd(Fr, Cc, oh, ow, seed=2)
-    # ATen derives the source coordinates in the tensor's dtype: the fp32 graph is the one the forward kernel matches
-    (ref,) = grad_of(lambda xx: F.interpolate(xx, (oh, ow), mode="bilinear", align_corners=True), [x], g, torch.float32)
+    Wy, Wx = interp_matrix(ih, oh), interp_matrix(iw, ow)
+    fwd = torch.einsum("oi,fcij,pj->fcop", Wy, x.double(), Wx)
+    torch_fwd = F.interpolate(x, (oh, ow), mode="bilinear", align_corners=True)
+    assert (fwd - torch_fwd.double()).abs().max().item() < 2e-6  # the matrices ARE the fp32 forward
+    ref = torch.einsum("oi,fcop,pj->fcij", Wy, g.double(), Wx)
     base = rnd(Fr, ih, iw, Cc, seed=3)
     gd = g.permute(0, 2, 3, 1).contiguous().to(cuda)
     dx = base.to(cuda) if acc else torch.full((Fr, ih, iw, Cc), float("nan"), device=cuda)
@@ -211,7 +234,8 @@ def test_attn_temporal_bwd(lib, cuda, Bc, T, P, Cc):
     close(dq, ref, 5e-6, "attn_temporal_bwd")
 
 
-@pytest.mark.parametrize("Fr,H,W,Cin,Cout", [(2, 37, 37, 64, 64), (1, 20, 28, 48, 32), (1, 5, 6, 32, 4)])
+@pytest.mark.parametrize("Fr,H,W,Cin,Cout", [(2, 37, 37, 64, 64), (1, 20, 28, 48, 32), (1, 5, 6, 32, 4), (2, 224, 280, 32, 32), (2, 128, 160, 64, 32),
+                                             (1, 64, 80, 48, 64)])
 def test_conv3x3_bwd_data_stride1(lib, cuda, Fr, H, W, Cin, Cout):
     x, w, g = rnd(Fr, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=0.1), rnd(Fr, Cout, H, W, seed=3)
     (ref,) = grad_of(lambda xx: F.conv2d(xx, w.double(), None, padding=1), [x], g)

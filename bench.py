@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with HIP events")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(16, cores): the box's CPU share)")
+    ap.add_argument("--train", action="store_true", help="time the fine-tune step instead (forward + loss + HIP backward + gradient "
+                    "all-reduce + AdamW on the LoRA factors; BASELINE.json config 4 shape with --encoder vitb --T 16); not the headline metric")
     return ap.parse_args()
 
 
@@ -122,6 +124,8 @@ def main():
         torch.cuda.synchronize(dev)
         parallel.barrier()
 
+    if args.train:
+        return train_bench(args, model, x, dev, rank, world, kwargs, sync_all)
     with torch.no_grad():
         for _ in range(max(args.warmup, 1)):
             out = model(x)
@@ -191,6 +195,58 @@ def main():
             line["cpu_baseline"] = cpu_baseline(kwargs, T, S, args.cpu_threads)
         else:
             line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        parallel.barrier()
+        dist.destroy_process_group()
+
+
+def train_bench(args, model, x, dev, rank, world, kwargs, sync_all):
+    """One fine-tune step per iteration: HIP forward keeping activations, a PyTorch loss on the four disparity maps (the
+    reference's losses stay PyTorch, north_star), HIP backward to the LoRA factors, ONE all-reduce of the flat gradient
+    buffer, AdamW.  One clip per GPU per step (the reference's DataParallel split, trainer_end_to_end_video.py:731)."""
+    import torch
+    import torch.distributed as dist
+
+    import endodav_amd
+    from endodav_amd import parallel
+
+    endodav_amd.mark_only_part_as_trainable(model, warm_up=True)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.AdamW(params, lr=1e-4)
+    T, S = args.T, args.image
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(x)
+        loss = sum((o - o.detach().mean()).abs().mean() for o in out.values())  # stand-in for the photometric loss: an L1 on every scale
+        loss.backward()
+        n = parallel.allreduce_gradients(params)
+        opt.step()
+        return loss, n
+
+    for _ in range(max(args.warmup, 1)):
+        loss, nred = step()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, nred = step()
+    torch.cuda.synchronize(dev)
+    parallel.barrier()
+    dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    if rank == 0:
+        frames = world * args.clips * T * args.steps
+        line = {
+            "metric": f"fine-tune frames/sec ({S}x{S}, T={T} clip, LoRA factors trainable)", "value": round(frames / dt, 2), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"ViT-{args.encoder[-1].upper()} endodav fine-tune step (dvlora r=4, VDA head): forward + L1 stand-in loss + HIP "
+                                   f"backward + gradient all-reduce + AdamW, {args.clips} synthetic {S}x{S} T={T} clip(s) per GPU per step",
+                       "encoder": args.encoder, "T": T, "image": [S, S], "clips_per_gpu_per_step": args.clips,
+                       "parallelism": f"data-parallel x{world}: one all-reduce of {nred} gradient floats per step"},
+            "trainable_floats": nred, "loss": float(loss.item()), "device_mem_mb": round(model.device_bytes() / 2 ** 20, 1),
+            "roofline": None, "cpu_baseline": None,
+        }
         print(json.dumps(line), flush=True)
     if world > 1:
         parallel.barrier()

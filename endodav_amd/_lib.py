@@ -91,6 +91,7 @@ SIGNATURES = {
     "edv_attn_temporal_bwd": (C.c_int, [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
     "edv_pack_conv3x3_bwd": (C.c_int, [_fp, _fp, _i32, _i32, C.c_void_p]),
     "edv_conv3x3_s2_bwd": (C.c_int, [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
+    "edv_dilate2": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, C.c_void_p]),
     "edv_pixel_unshuffle": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
     "edv_attn_temporal": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
     "edv_groupnorm": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _f32, C.c_void_p]),

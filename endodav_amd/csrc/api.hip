@@ -128,6 +128,9 @@ int edv_conv3x3_s2_bwd(const float *dy_dev, const float *wpacked_dev, float *dx_
                        void *stream) {
     return conv3x3_s2_bwd(dy_dev, wpacked_dev, dx_dev, F, H, W, Cin, Cout, (hipStream_t)stream);
 }
+int edv_dilate2(const float *dy_dev, float *z_dev, int32_t F, int32_t H, int32_t W, int32_t C, void *stream) {
+    return dilate2(dy_dev, z_dev, F, H, W, C, (hipStream_t)stream);
+}
 int edv_pixel_unshuffle(const float *dy_dev, float *A_dev, int32_t F, int32_t h, int32_t w, int32_t C, int32_t s, void *stream) {
     return pixel_unshuffle(dy_dev, A_dev, F, h, w, C, s, (hipStream_t)stream);
 }

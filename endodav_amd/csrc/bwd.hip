@@ -382,6 +382,7 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_apply_kernel(const float *_
 }
 
 // ---- temporal attention backward (temporal.hip attn_temporal_kernel): one thread per (clip, pixel, head), all T queries --
+// float4 over the head dimension (d % 4 == 0); dK / dV rows are accumulated in place (this thread owns them).
 template <int TMAX>
 __global__ __launch_bounds__(64) void attn_temporal_bwd_kernel(const float *__restrict__ qkv, const float *__restrict__ dout, float *__restrict__ dqkv, int B,
                                                                int T, int P, int C, int heads, float scale) {
@@ -399,23 +400,24 @@ __global__ __launch_bounds__(64) void attn_temporal_bwd_kernel(const float *__re
     const float *gb = dout + ((long long)(b * T) * P + p) * C + head * d;
     float *dqb = dqkv + ((long long)(b * T) * P + p) * C3 + head * d;
     float *dkb = dqb + C, *dvb = dqb + 2 * C;
-    // dK and dV rows accumulate over the queries: zero them first (this thread owns them)
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < T; ++t)
-        for (int c = 0; c < d; ++c) {
-            dkb[t * ts3 + c] = 0.f;
-            dvb[t * ts3 + c] = 0.f;
+        for (int c = 0; c < d; c += 4) {
+            *reinterpret_cast<f32x4 *>(dkb + t * ts3 + c) = zero;
+            *reinterpret_cast<f32x4 *>(dvb + t * ts3 + c) = zero;
         }
     for (int tq = 0; tq < T; ++tq) {
         float s[TMAX], dp[TMAX];
 #pragma unroll
         for (int ts = 0; ts < TMAX; ++ts) s[ts] = dp[ts] = 0.f;
-        for (int c = 0; c < d; ++c) {
-            const float q = qb[tq * ts3 + c], g = gb[tq * ts1 + c];
+        for (int c = 0; c < d; c += 4) {
+            const f32x4 q = *reinterpret_cast<const f32x4 *>(qb + tq * ts3 + c), g = *reinterpret_cast<const f32x4 *>(gb + tq * ts1 + c);
 #pragma unroll
             for (int ts = 0; ts < TMAX; ++ts)
                 if (ts < T) {
-                    s[ts] += q * kb[ts * ts3 + c];
-                    dp[ts] += g * vb[ts * ts3 + c];
+                    const f32x4 k = *reinterpret_cast<const f32x4 *>(kb + ts * ts3 + c), v = *reinterpret_cast<const f32x4 *>(vb + ts * ts3 + c);
+                    s[ts] += (q.x * k.x + q.y * k.y) + (q.z * k.z + q.w * k.w);
+                    dp[ts] += (g.x * v.x + g.y * v.y) + (g.z * v.z + g.w * v.w);
                 }
         }
         float mx = -INFINITY;
@@ -443,18 +445,38 @@ __global__ __launch_bounds__(64) void attn_temporal_bwd_kernel(const float *__re
 #pragma unroll
         for (int ts = 0; ts < TMAX; ++ts)
             if (ts < T) dp[ts] = s[ts] * (dp[ts] - dot) * scale;  // dS * scale
-        for (int c = 0; c < d; ++c) {
-            const float q = qb[tq * ts3 + c], g = gb[tq * ts1 + c];
-            float dq = 0.f;
+        for (int c = 0; c < d; c += 4) {
+            const f32x4 q = *reinterpret_cast<const f32x4 *>(qb + tq * ts3 + c), g = *reinterpret_cast<const f32x4 *>(gb + tq * ts1 + c);
+            f32x4 dq = zero;
 #pragma unroll
             for (int ts = 0; ts < TMAX; ++ts)
                 if (ts < T) {
-                    dq += dp[ts] * kb[ts * ts3 + c];
-                    dkb[ts * ts3 + c] += dp[ts] * q;
-                    dvb[ts * ts3 + c] += s[ts] * g;
+                    dq += dp[ts] * *reinterpret_cast<const f32x4 *>(kb + ts * ts3 + c);
+                    f32x4 *dk = reinterpret_cast<f32x4 *>(dkb + ts * ts3 + c), *dv = reinterpret_cast<f32x4 *>(dvb + ts * ts3 + c);
+                    *dk += dp[ts] * q;
+                    *dv += s[ts] * g;
                 }
-            dqb[tq * ts3 + c] = dq;
+            *reinterpret_cast<f32x4 *>(dqb + tq * ts3 + c) = dq;
         }
+    }
+}
+
+// zero insertion of a stride-2 convolution's output gradient: z[f, 2*oy, 2*ox, :] = dy[f, oy, ox, :], zero elsewhere; the
+// stride-2 input gradient is then the stride-1 input-gradient convolution of z (flipped taps)
+__global__ __launch_bounds__(256) void dilate2_kernel(const float *__restrict__ dy, float *__restrict__ z, int F, int H, int W, int C, int OH, int OW) {
+    const int c4n = C >> 2;
+    const long long total = (long long)F * H * W * c4n;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % c4n) * 4;
+        long long r = i / c4n;
+        const int x = (int)(r % W);
+        r /= W;
+        const int y = (int)(r % H);
+        const int f = (int)(r / H);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (!(y & 1) && !(x & 1) && (y >> 1) < OH && (x >> 1) < OW)
+            v = *reinterpret_cast<const f32x4 *>(dy + (((long long)f * OH + (y >> 1)) * OW + (x >> 1)) * C + c);
+        *reinterpret_cast<f32x4 *>(z + i * 4) = v;
     }
 }
 
@@ -685,7 +707,7 @@ int groupnorm_bwd(const float *x, const float *stats, const float *w, const floa
 
 int attn_temporal_bwd(const float *qkv, const float *dout, float *dqkv, int B, int T, int P, int C, int heads, hipStream_t st) {
     EDV_CHECK(qkv && dout && dqkv, "null operand");
-    EDV_CHECK(B > 0 && T > 0 && T <= 32 && P > 0 && C > 0 && heads > 0 && C % heads == 0, "shape");
+    EDV_CHECK(B > 0 && T > 0 && T <= 32 && P > 0 && C > 0 && heads > 0 && C % heads == 0 && (C / heads) % 4 == 0, "shape (head dim % 4)");
     const long long total = (long long)B * P * heads;
     const long long blocks = (total + 63) / 64;
     EDV_CHECK(blocks < (1ll << 31), "grid");
@@ -715,6 +737,15 @@ int conv3x3_s2_bwd(const float *dy, const float *wpacked, float *dx, int F, int 
     const long long total = (long long)F * H * W * Cin;
     EDV_CHECK((total + 255) / 256 < (1ll << 31), "grid");
     hipLaunchKernelGGL(conv3x3_s2_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, wpacked, dx, F, H, W, Cin, Cout, OH, OW);
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
+int dilate2(const float *dy, float *z, int F, int H, int W, int C, hipStream_t st) {
+    EDV_CHECK(dy && z && F > 0 && H > 0 && W > 0 && C % 4 == 0, "shape");
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const long long total = (long long)F * H * W * (C / 4);
+    hipLaunchKernelGGL(dilate2_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, dy, z, F, H, W, C, OH, OW);
     EDV_LAUNCH_OK();
     return 0;
 }

@@ -135,6 +135,7 @@ int groupnorm_bwd(const float *x, const float *stats, const float *w, const floa
 int attn_temporal_bwd(const float *qkv, const float *dout, float *dqkv, int B, int T, int P, int C, int heads, hipStream_t st);
 int pixel_unshuffle(const float *dy, float *A, int F, int h, int w, int C, int s, hipStream_t st);
 int conv3x3_s2_bwd(const float *dy, const float *wpacked, float *dx, int F, int H, int W, int Cin, int Cout, hipStream_t st);
+int dilate2(const float *dy, float *z, int F, int H, int W, int C, hipStream_t st);  // z[f,2oy,2ox] = dy[f,oy,ox], zeros elsewhere
 int pack_conv3x3_bwd(const float *w, float *out, int Cout, int Cin, hipStream_t st);  // [Co,Ci,3,3] -> [Ci][3][3][Co], taps flipped
 
 }  // namespace edv

@@ -1,4 +1,5 @@
-"""Clip sharding across GPUs: one process per GPU, no data-path collective.
+"""Clip sharding across GPUs: one process per GPU.  Inference has no data-path collective; the
+fine-tune step has exactly one: an all-reduce of the trainable gradients (``allreduce_gradients``).
 
 ``forward`` never mixes clips (the encoder treats B*T as a flat batch and the motion modules attend
 within a clip only: dpt_pyramid.py:71-74, motion_module.py:232), and the windows of a long video depend on
@@ -70,3 +71,34 @@ def merge_shards(shards: Sequence[Sequence[Any]], n_units: int) -> List[Any]:
         for i, v in zip(idx, items):
             out[i] = v
     return out
+
+
+def allreduce_gradients(params: Sequence[torch.nn.Parameter]) -> int:
+    """Data-parallel fine-tune step, one clip per rank (the reference scatters dim 0 of [batch, T, ...] over
+    ``nn.DataParallel`` replicas, trainer_end_to_end_video.py:731, and sums their gradients): ONE all-reduce over a flat
+    fp32 buffer of every trainable gradient -- a few MB of LoRA factors -- summed, then divided by the world size.
+    A parameter without a gradient on this rank contributes zeros.  Returns the number of floats reduced."""
+    params = [p for p in params if p.requires_grad]
+    if not params:
+        return 0
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    n = sum(p.numel() for p in params)
+    if world == 1:
+        return n
+    flat = torch.zeros(n, dtype=torch.float32, device=params[0].device)
+    off = 0
+    for p in params:
+        if p.grad is not None:
+            flat[off:off + p.numel()].copy_(p.grad.reshape(-1))
+        off += p.numel()
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    flat /= world
+    off = 0
+    for p in params:
+        g = flat[off:off + p.numel()].view_as(p)
+        if p.grad is None:
+            p.grad = g.clone()
+        else:
+            p.grad.copy_(g)
+        off += p.numel()
+    return n

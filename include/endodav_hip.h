@@ -245,6 +245,9 @@ int edv_attn_temporal_bwd(const float *qkv_dev, const float *dout_dev, float *dq
 int edv_pack_conv3x3_bwd(const float *w_dev, float *wpacked_dev, int32_t Cout, int32_t Cin, void *stream);
 int edv_conv3x3_s2_bwd(const float *dy_dev, const float *wpacked_dev, float *dx_dev, int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
                        void *stream);
+/* The engine's form of the stride-2 input gradient: z [F,H,W,C] = dy [F,OH,OW,C] with zeros inserted (z[2oy,2ox] = dy[oy,ox]),
+ * then the stride-1 recipe above on z. */
+int edv_dilate2(const float *dy_dev, float *z_dev, int32_t F, int32_t H, int32_t W, int32_t C, void *stream);
 /* ConvTranspose(k = s) input gradient = edv_gemm of the pixel-unshuffled dy [F*h*w, s*s*C] with the transposed packed weight. */
 int edv_pixel_unshuffle(const float *dy_dev, float *A_dev, int32_t F, int32_t h, int32_t w, int32_t C, int32_t s, void *stream);
 

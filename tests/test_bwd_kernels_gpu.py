@@ -259,6 +259,14 @@ def test_conv3x3_s2_bwd(lib, cuda, Fr, H, W, Cc):
     dx = torch.full((Fr, H, W, Cc), float("nan"), device=cuda)
     _lib.check(lib.edv_conv3x3_s2_bwd(gd.data_ptr(), wp.data_ptr(), dx.data_ptr(), Fr, H, W, Cc, Cc, st()))
     close(dx.permute(0, 3, 1, 2), ref, 3e-6, "conv3x3 s2 bwd-data")
+    # the engine's route: zero insertion + the stride-1 input-gradient convolution on the MFMA path
+    z = torch.full((Fr, H, W, Cc), float("nan"), device=cuda)
+    _lib.check(lib.edv_dilate2(gd.data_ptr(), z.data_ptr(), Fr, H, W, Cc, st()))
+    wb = torch.empty(Cc * 9 * Cc, device=cuda)
+    _lib.check(lib.edv_pack_conv3x3_bwd(keep(w.to(cuda)), wb.data_ptr(), Cc, Cc, st()))
+    dx2 = torch.full((Fr, H, W, Cc), float("nan"), device=cuda)
+    _lib.check(lib.edv_conv3x3(z.data_ptr(), wb.data_ptr(), None, dx2.data_ptr(), Fr, H, W, Cc, Cc, 1, 0, 0, None, None, st()))
+    close(dx2.permute(0, 3, 1, 2), ref, 3e-6, "conv3x3 s2 bwd-data via dilation")
 
 
 @pytest.mark.parametrize("Fr,h,w,Cc,s", [(2, 37, 37, 48, 4), (1, 16, 20, 96, 2)])

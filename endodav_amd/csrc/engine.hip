@@ -369,7 +369,7 @@ struct Run {
         EDV_TRY(wsbuf("mm.hn", (size_t)M * C, &hn));
         EDV_TRY(wsbuf("mm.att", (size_t)M * C, &att));
         EDV_TRY(wsbuf(tg + "ff1", (size_t)M * 8 * C, &ff1));
-        EDV_TRY(wsbuf("mm.ff2", (size_t)M * 4 * C, &ff2));
+        EDV_TRY(wsbuf(c->train ? tg + "ff2" : std::string("mm.ff2"), (size_t)M * 4 * C, &ff2));  // input of ff.net.2: its LoRA gradient needs it
         EDV_TRY(wsbuf(tg + "stats", (size_t)F * 32 * 2, &stats));
         const float *w, *b;
         EDV_TRY(param(p + ".norm.weight", &w));
@@ -857,6 +857,8 @@ struct Run {
     // Backward.  Trainable: the LoRA / DV-LoRA factors of mlp.fc1 / mlp.fc2 in every encoder
     // block (endodav/layers.py:5-34 names lora_A, lora_B, lora_U, lora_V); everything else is frozen, so each operator
     // contributes its input gradient only.  Mirrors forward() in reverse on the activations a training forward kept.
+    float *lora_ws = nullptr;  // workspace of lora_grads for the whole backward
+    size_t lora_ws_n = 0;
     int gradbuf(const std::string &name, size_t n, float **out) { return alloc_buf(c, c->grads, name, n, st, out); }
     int saved(const std::string &name, const float **out) {
         auto it = c->ws.find(name);
@@ -889,8 +891,8 @@ struct Run {
     }
     int prepare_train() {
         EDV_CHECK(c->prepared, "edv_prepare has not run");
-        EDV_CHECK(!cfg.conv_head && !cfg.use_clstoken && !cfg.residual_mask && !cfg.temporal_lora && !cfg.out_sigmoid,
-                  "training supports the VDA head without use_clstoken / residual blocks / temporal_lora / out_sigmoid");
+        EDV_CHECK(!cfg.conv_head && !cfg.use_clstoken && !cfg.residual_mask && !cfg.out_sigmoid,
+                  "training supports the VDA head without use_clstoken / residual blocks / out_sigmoid");
         EDV_CHECK(cfg.lora_type == EDV_LORA_NONE || cfg.lora_type == EDV_LORA_LORA || cfg.lora_type == EDV_LORA_DVLORA,
                   "training supports lora_type none, lora and dvlora");
         const int *oc = cfg.out_channels;
@@ -980,6 +982,11 @@ struct Run {
         EDV_TRY(saved(tg + "qkv1", &qkvs[1]));
         EDV_TRY(saved(tg + "ff1", &ff1));
         EDV_TRY(dgemm(d, M, C, p + ".proj_out", C, dh));                   // x = xin + proj_out(h3)
+        if (cfg.temporal_lora && cfg.lora_type != EDV_LORA_NONE) {        // temporal LoRA on ff.net.2 (endodav.py:119-137)
+            const float *ff2;
+            EDV_TRY(saved(tg + "ff2", &ff2));
+            EDV_TRY(lora_step(tb + ".ff.net.2", ff2, 4 * C, dh, C, M, cfg.lora_rank, cfg.lora_type == EDV_LORA_LORA ? 2.0f : 1.0f, "", lora_ws, lora_ws_n));
+        }
         EDV_TRY(dgemm(dh, M, C, tb + ".ff.net.2", 4 * C, t4));             // h3 = h2 + ff2 W2
         EDV_TRY(geglu_bwd(ff1, t4, t8, M, 4 * C, st));
         EDV_TRY(dgemm(t8, M, 8 * C, tb + ".ff.net.0.proj", C, t1));
@@ -1043,6 +1050,22 @@ struct Run {
         const int h0 = 8 * ph, w0 = 8 * pw, ih = cfg.image_h, iw = cfg.image_w, Fh = Fe / 2;
         skws = nullptr;
         skws_floats = 0;
+        {   // one workspace for every LoRA-gradient call: encoder MLPs (M = F*ntok, D <-> 4D) and, with temporal_lora, ff.net.2
+            size_t need = 4;
+            if (cfg.lora_type != EDV_LORA_NONE) {
+                need = lora_grads_workspace(MT, D, 4 * D, cfg.lora_rank);
+                if (cfg.temporal_lora) {
+                    const long long Ms[4] = {(long long)F * h3 * w3, (long long)F * h4 * w4, (long long)F * h3 * w3, (long long)F * h2 * w2};
+                    const int Cs[4] = {oc[2], oc[3], Fe, Fe};
+                    for (int m = 0; m < 4; ++m) {
+                        const size_t n = lora_grads_workspace(Ms[m], 4 * Cs[m], Cs[m], cfg.lora_rank);
+                        need = n > need ? n : need;
+                    }
+                }
+            }
+            EDV_TRY(wsbuf("g.lora", need, &lora_ws));
+            lora_ws_n = need;
+        }
 
         // ---------------- output head: disp[k] = down(disp[k-1]); disp[0] = relu(dot(relu(conv2(up(conv1(p1)))))) ----
         int sh[4], sw[4];
@@ -1131,8 +1154,8 @@ struct Run {
         EDV_TRY(wsbuf("g.delta", (size_t)F * heads * ntok, &delta));
         const int rank = cfg.lora_rank;
         const bool lora = cfg.lora_type != EDV_LORA_NONE;
-        const size_t lws_n = lora ? lora_grads_workspace(MT, D, 4 * D, rank) : 4;
-        EDV_TRY(wsbuf("g.lora", lws_n, &lws));
+        const size_t lws_n = lora_ws_n;
+        lws = lora_ws;
         EDV_HIP(hipMemsetAsync(dxt, 0, (size_t)MT * D * sizeof(float), st));
         const float lscale = cfg.lora_type == EDV_LORA_LORA ? 2.0f : 1.0f;  // lora_alpha / r (endodav.py:108-112)
         const float *nw;
@@ -1285,8 +1308,8 @@ int edv_forward(edv_ctx *ctx, const float *x_dev, int32_t B, int32_t T, int32_t 
     for (int k = 0; k < 4; ++k) EDV_CHECK(disp_dev[k], "null output");
     if (ctx->train) {
         const edv_config &c = ctx->cfg;
-        EDV_CHECK(!c.conv_head && !c.use_clstoken && !c.residual_mask && !c.temporal_lora && !c.out_sigmoid,
-                  "training supports the VDA head without use_clstoken / residual blocks / temporal_lora / out_sigmoid");
+        EDV_CHECK(!c.conv_head && !c.use_clstoken && !c.residual_mask && !c.out_sigmoid,
+                  "training supports the VDA head without use_clstoken / residual blocks / out_sigmoid");
         EDV_CHECK(c.lora_type == EDV_LORA_NONE || c.lora_type == EDV_LORA_LORA || c.lora_type == EDV_LORA_DVLORA,
                   "training supports lora_type none, lora and dvlora");
         EDV_CHECK(!ctx->capture, "stage capture and training are exclusive");

@@ -577,10 +577,11 @@ class endodav(nn.Module):
         gradients of the LoRA factors of mlp.fc1 / mlp.fc2 (what ``mark_only_part_as_trainable`` leaves trainable for
         lora / dvlora, endodav/layers.py:5-34); a trainable parameter outside that set is refused, not silently frozen."""
         names = [n for n, p in self.state_dict(keep_vars=True).items() if p.requires_grad]
-        bad = [n for n in names if not (".mlp.fc" in n and n.rsplit(".", 1)[-1] in ("lora_A", "lora_B", "lora_U", "lora_V"))]
+        bad = [n for n in names if not ((".mlp.fc" in n or ".ff.net.2." in n) and n.rsplit(".", 1)[-1] in ("lora_A", "lora_B", "lora_U", "lora_V"))]
         if bad:
             raise NotImplementedError(f"libendodav_hip has no gradient for {bad[:4]}{' ...' if len(bad) > 4 else ''}: only the LoRA factors of the "
-                                      "encoder MLPs are trainable through the HIP backward (SURVEY.md §8f rank 3)")
+                                      "encoder MLPs (and, with temporal_lora, of ff.net.2 in the motion modules) are trainable through the HIP "
+                                      "backward (SURVEY.md §8f rank 3)")
         if names and self.lora_type not in ("lora", "dvlora"):
             raise NotImplementedError(f"the HIP backward supports lora_type 'lora' and 'dvlora', not {self.lora_type!r}")
         return names

@@ -1,9 +1,10 @@
 """Fine-tune step on MI355X: edv_forward under edv_set_train + edv_backward against torch
 autograd through the CPU oracle on the same weights, inputs and upstream gradients.
 
-Gate: every LoRA-factor gradient within 2e-4 of the largest entry of its reference tensor.  Both sides run fp32; the
-gradient passes through ~60 ReLU / GELU / softmax stages whose masks can flip at fp32-noise zero crossings, which is
-what sets the floor (the per-kernel tests in test_bwd_kernels_gpu.py hold 2e-6 .. 1e-5 each)."""
+Gate: every LoRA-factor gradient within 2e-4 of the largest entry of its reference tensor (micro configurations, fp32
+oracle) / 1e-3 (full size, fp64 oracle).  The gradient passes through ~60 ReLU stages whose masks can flip at fp32-noise
+zero crossings; see ``upstream`` for why the tests feed a gradient with a definite sign, and test_bwd_kernels_gpu.py for
+the per-kernel gates (2e-6 .. 1e-5, random-sign gradients)."""
 import numpy as np
 import pytest
 import torch
@@ -18,8 +19,12 @@ pytestmark = pytest.mark.gpu
 FACTORS = ("lora_A", "lora_B", "lora_U", "lora_V")
 
 
-def upstream(shapes, seed=5):
-    return [torch.from_numpy(synth.uniform(f"gout{k}", tuple(s), -1.0, 1.0, seed=seed)) for k, s in enumerate(shapes)]
+def upstream(shapes, seed=5, signed=False):
+    """dL/d("disp", k).  Default 1 + 0.5 U(-1, 1): a gradient with a definite sign, as a loss has.  ``signed=True`` gives
+    U(-1, 1): then the factor gradients are an incoherent sum over the output pixels and ONE ReLU mask that flips at an
+    fp32-noise zero crossing moves all of them by ~1/sqrt(pixels) (1e-3 .. 1e-2 here) -- in the fp32 reference as well."""
+    g = [torch.from_numpy(synth.uniform(f"gout{k}", tuple(s), -1.0, 1.0, seed=seed)) for k, s in enumerate(shapes)]
+    return g if signed else [1.0 + 0.5 * t for t in g]
 
 
 def oracle_grads(model, kwargs, x, names, gouts, dtype=torch.float32):
@@ -43,7 +48,7 @@ def hip_grads(model, x, names, gouts, cuda):
 def set_trainable(model, tags):
     names = []
     for n, p in model.named_parameters():
-        p.requires_grad = ".mlp.fc" in n and n.rsplit(".", 1)[-1] in tags
+        p.requires_grad = (".mlp.fc" in n or ".ff.net.2." in n) and n.rsplit(".", 1)[-1] in tags
         if p.requires_grad:
             names.append(n)
     return names
@@ -60,7 +65,7 @@ def check(hip, ref, tol=2e-4):
     return worst
 
 
-@pytest.mark.parametrize("case", ["micro_vda_dvlora", "micro_vda_lora_b2", "micro_t1"])
+@pytest.mark.parametrize("case", ["micro_vda_dvlora", "micro_vda_lora_b2", "micro_t1", "micro_vda_temporal_lora"])
 def test_lora_gradients_match_oracle_autograd(lib, cuda, case):
     model, kwargs, shape, kind, _ = build_model(case)
     x = case_input(case)
@@ -83,7 +88,7 @@ def test_vits_gradients_full_size(lib, cuda, H, W, T, resize_from):
     """ViT-S at the trainer's 256x320 -> (224, 280) geometry (BASELINE config 4) and at 518x518, against the oracle's
     autograd in fp64.
 
-    The upstream gradient is positive (1 + 0.5 U(-1,1)) on purpose.  With a random-SIGN upstream gradient the factor
+    The upstream gradient has a definite sign (see ``upstream``).  With a random-SIGN upstream gradient the factor
     gradients are an incoherent sum over ~10^5 output pixels and a single ReLU whose pre-activation sits within fp32
     noise of zero (here: one element of 4 M in output_conv2, +1e-5 on the GPU, exactly 0 in fp64) moves every one of
     them by ~1e-3 of its scale -- the fp32 CPU oracle shows the same sensitivity (1e-3 .. 7e-3 against its own fp64 run
@@ -97,7 +102,7 @@ def test_vits_gradients_full_size(lib, cuda, H, W, T, resize_from):
     h_in, w_in = resize_from or (H, W)
     x = torch.from_numpy(synth.synth_clip(1, T, h_in, w_in, seed=3, kind="tissue"))
     model = model.to(cuda).train()
-    gouts = [1.0 + 0.5 * g for g in upstream([(T, 1, h, w) for (h, w) in model.output_shapes()])]
+    gouts = upstream([(T, 1, h, w) for (h, w) in model.output_shapes()])
     ref64, _ = oracle_grads(model, kwargs, x, names, gouts, torch.float64)
     hip, _ = hip_grads(model, x, names, gouts, cuda)
     worst = check(hip, ref64, tol=1e-3)
@@ -129,7 +134,7 @@ def test_freeze_schedule_selects_the_gradient_set(lib, cuda):
         sum(o.sum() for o in out.values()).backward()
         for n, p in model.named_parameters():
             tag = n.rsplit(".", 1)[-1]
-            if ".mlp.fc" in n and tag in on:
+            if (".mlp.fc" in n or ".ff.net.2." in n) and tag in on:
                 assert p.grad is not None and torch.isfinite(p.grad).all() and p.grad.abs().max() > 0, n
             else:
                 assert p.grad is None, n

@@ -557,6 +557,30 @@ __global__ __launch_bounds__(256) void lora_factors_kernel(const float *__restri
     }
 }
 
+// ---- Linear_SSB (mylora/layers.py:396-430): W' = b * W * a^T with a = lora_A [in, 1], b = lora_B [out, 1] -------------------
+// Wa[n, k] = W[n, k] * a[k]  (weight of z = (x * a) W^T);   gb[n] = gamma[n] * b[n]  (row scale of the transposed weight of u)
+__global__ __launch_bounds__(256) void ssb_prep_kernel(const float *__restrict__ W, const float *__restrict__ a, const float *__restrict__ b,
+                                                       const float *__restrict__ gamma, float *__restrict__ Wa, float *__restrict__ gb, int nout, int nin) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < (long long)nout * nin) Wa[i] = W[i] * a[i % nin];
+    if (i < nout) gb[i] = b[i] * (gamma ? gamma[i] : 1.f);
+}
+// part[s, n] = sum_{m in split s} P[m, n] * Q[m, n]
+__global__ __launch_bounds__(256) void col_dot_partial_kernel(const float *__restrict__ P, const float *__restrict__ Q, long long M, int N,
+                                                              float *__restrict__ part, int rows_per_split) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + lane;
+    const long long mb = (long long)blockIdx.y * rows_per_split;
+    const long long me = mb + rows_per_split < M ? mb + rows_per_split : M;
+    float acc = 0.f;
+    if (n < N)
+        for (long long m = mb + wv; m < me; m += 4) acc += P[m * N + n] * Q[m * N + n];
+    red[wv][lane] = acc;
+    __syncthreads();
+    if (wv == 0 && n < N) part[(long long)blockIdx.y * N + n] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
 int ew_blocks(long long n) { return (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); }
 
 }  // namespace
@@ -668,6 +692,26 @@ int lora_grads(const float *X, int ldx, const float *G, int ldg, long long M, in
     EDV_TRY(tall_tn(G, ldg, t, M, nout, r, s, gamma, part, dBp, st));
     EDV_TRY(tall_tn(X, ldx, u, M, nin, r, s, nullptr, part, dApT, st));
     return lora_grad_finalize(dBp, dApT, A, Bm, U, V, dA, dB, dU, dV, nout, nin, r, st);
+}
+
+int ssb_prep(const float *W, const float *a, const float *b, const float *gamma, float *Wa, float *gb, int nout, int nin, hipStream_t st) {
+    EDV_CHECK(W && a && b && Wa && gb && nout > 0 && nin > 0, "shape");
+    const long long n = (long long)nout * nin;
+    hipLaunchKernelGGL(ssb_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, a, b, gamma, Wa, gb, nout, nin);
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
+// out[n] = scale[n] * sum_m P[m, n] Q[m, n]  (deterministic two-stage reduction; part: TALL_SPLITS * N floats)
+int col_dot(const float *P, const float *Q, long long M, int N, const float *scale, float *part, float *out, hipStream_t st) {
+    EDV_CHECK(P && Q && part && out && M > 0 && N > 0, "shape");
+    const int rows_per_split = (int)((M + TALL_SPLITS - 1) / TALL_SPLITS);
+    const int splits = (int)((M + rows_per_split - 1) / rows_per_split);
+    hipLaunchKernelGGL(col_dot_partial_kernel, dim3((N + 63) / 64, splits), dim3(256), 0, st, P, Q, M, N, part, rows_per_split);
+    EDV_LAUNCH_OK();
+    hipLaunchKernelGGL(tall_tn_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part, splits, N, 1, 1.0f, scale, out);
+    EDV_LAUNCH_OK();
+    return 0;
 }
 
 int bilinear_bwd(const float *dy, float *dx, int F, int ih, int iw, int C, int oh, int ow, bool accumulate, hipStream_t st) {

@@ -893,8 +893,7 @@ struct Run {
         EDV_CHECK(c->prepared, "edv_prepare has not run");
         EDV_CHECK(!cfg.conv_head && !cfg.use_clstoken && !cfg.residual_mask && !cfg.out_sigmoid,
                   "training supports the VDA head without use_clstoken / residual blocks / out_sigmoid");
-        EDV_CHECK(cfg.lora_type == EDV_LORA_NONE || cfg.lora_type == EDV_LORA_LORA || cfg.lora_type == EDV_LORA_DVLORA,
-                  "training supports lora_type none, lora and dvlora");
+        EDV_CHECK(cfg.lora_type != EDV_LORA_DASH, "training supports lora_type none, lora, dvlora and ssb");
         const int *oc = cfg.out_channels;
         for (int i = 0; i < depth; ++i) {
             const std::string bp = "pretrained.blocks." + std::to_string(i);
@@ -1197,10 +1196,38 @@ struct Run {
         c->have_saved = false;
         return 0;
     }
+    // Linear_SSB (mylora/layers.py:396-430), y = gamma * (((x * a) W^T) * b + bias):  with z = (x * a) W^T and
+    // u = (G * gamma * b) W:   db[n] = gamma[n] sum_m G[m,n] z[m,n],   da[k] = sum_m x[m,k] u[m,k].
+    // Two extra GEMMs per linear (a and b may pass through zero, so neither is recovered by dividing y or dX).
+    int ssb_step(const std::string &p, const float *X, int nin, const float *G, int nout, long long M, const std::string &gamma_name) {
+        const float *W, *a, *b, *gam = nullptr;
+        EDV_TRY(param(p + ".weight", &W, 2));
+        EDV_TRY(param(p + ".lora_A", &a));
+        EDV_TRY(param(p + ".lora_B", &b));
+        if (!gamma_name.empty()) EDV_TRY(param(gamma_name, &gam));
+        float *Wa, *gb, *Tu, *z, *u, *part, *da, *db;
+        EDV_TRY(wsbuf("g.ssb.wa", (size_t)nout * nin, &Wa));
+        EDV_TRY(wsbuf("g.ssb.tu", (size_t)nout * nin, &Tu));
+        EDV_TRY(wsbuf("g.ssb.gb", (size_t)nout, &gb));
+        EDV_TRY(wsbuf("g.ssb.z", (size_t)M * nout, &z));
+        EDV_TRY(wsbuf("g.ssb.u", (size_t)M * nin, &u));
+        EDV_TRY(wsbuf("g.ssb.part", (size_t)TALL_SPLITS * (nin > nout ? nin : nout), &part));
+        EDV_TRY(gradbuf(p + ".lora_A", (size_t)nin, &da));
+        EDV_TRY(gradbuf(p + ".lora_B", (size_t)nout, &db));
+        EDV_TRY(ssb_prep(W, a, b, gam, Wa, gb, nout, nin, st));
+        EDV_TRY(transpose_scale(W, nin, gb, Tu, nout, nin, st));          // Tu [nin, nout] = (gamma b W)^T
+        EDV_TRY(linear(X, M, nin, Wa, nout, nullptr, z));                 // z = (x * a) W^T
+        EDV_TRY(linear(G, M, nout, Tu, nin, nullptr, u));                 // u = (G gamma b) W
+        EDV_TRY(col_dot(G, z, M, nout, gam, part, db, st));
+        EDV_TRY(col_dot(X, u, M, nin, nullptr, part, da, st));
+        c->launches += 6;
+        return 0;
+    }
     // gradients of the LoRA factors of one linear into c->grads["<p>.lora_A"] ... (mylora/layers.py:148-157, 384-393)
     int lora_step(const std::string &p, const float *X, int nin, const float *G, int nout, long long M, int r, float s, const std::string &gamma_name,
                   float *lws, size_t lws_n) {
         if (!has(p + ".lora_A")) return 0;
+        if (cfg.lora_type == EDV_LORA_SSB) return ssb_step(p, X, nin, G, nout, M, gamma_name);
         const float *A, *Bm, *U = nullptr, *V = nullptr, *gam = nullptr;
         EDV_TRY(param(p + ".lora_A", &A));
         EDV_TRY(param(p + ".lora_B", &Bm));
@@ -1310,8 +1337,7 @@ int edv_forward(edv_ctx *ctx, const float *x_dev, int32_t B, int32_t T, int32_t 
         const edv_config &c = ctx->cfg;
         EDV_CHECK(!c.conv_head && !c.use_clstoken && !c.residual_mask && !c.out_sigmoid,
                   "training supports the VDA head without use_clstoken / residual blocks / out_sigmoid");
-        EDV_CHECK(c.lora_type == EDV_LORA_NONE || c.lora_type == EDV_LORA_LORA || c.lora_type == EDV_LORA_DVLORA,
-                  "training supports lora_type none, lora and dvlora");
+        EDV_CHECK(c.lora_type != EDV_LORA_DASH, "training supports lora_type none, lora, dvlora and ssb");
         EDV_CHECK(!ctx->capture, "stage capture and training are exclusive");
     }
     Run r(ctx, (hipStream_t)stream);

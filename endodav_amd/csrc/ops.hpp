@@ -128,6 +128,9 @@ int lora_grad_finalize(const float *dBp, const float *dApT, const float *A, cons
 size_t lora_grads_workspace(long long M, int nin, int nout, int r);  // floats
 int lora_grads(const float *X, int ldx, const float *G, int ldg, long long M, int nin, int nout, int r, const float *A, const float *Bm, const float *U,
                const float *V, float s, const float *gamma, float *ws, size_t ws_floats, float *dA, float *dB, float *dU, float *dV, hipStream_t st);
+// Linear_SSB: Wa = W * a^T, gb = gamma * b;  col_dot: out[n] = scale[n] * sum_m P[m,n] Q[m,n] (part: TALL_SPLITS * N floats)
+int ssb_prep(const float *W, const float *a, const float *b, const float *gamma, float *Wa, float *gb, int nout, int nin, hipStream_t st);
+int col_dot(const float *P, const float *Q, long long M, int N, const float *scale, float *part, float *out, hipStream_t st);
 int bilinear_bwd(const float *dy, float *dx, int F, int ih, int iw, int C, int oh, int ow, bool accumulate, hipStream_t st);
 int dot_channels_bwd(const float *g, const float *disp, const float *w, const float *o2, float *d_o2, long long npix, int C, hipStream_t st);
 int groupnorm_bwd(const float *x, const float *stats, const float *w, const float *dy, float *sums, float *dx, int F, int P, int C, int groups, bool accumulate,

@@ -582,8 +582,8 @@ class endodav(nn.Module):
             raise NotImplementedError(f"libendodav_hip has no gradient for {bad[:4]}{' ...' if len(bad) > 4 else ''}: only the LoRA factors of the "
                                       "encoder MLPs (and, with temporal_lora, of ff.net.2 in the motion modules) are trainable through the HIP "
                                       "backward (SURVEY.md §8f rank 3)")
-        if names and self.lora_type not in ("lora", "dvlora"):
-            raise NotImplementedError(f"the HIP backward supports lora_type 'lora' and 'dvlora', not {self.lora_type!r}")
+        if names and self.lora_type not in ("lora", "dvlora", "ssb"):
+            raise NotImplementedError(f"the HIP backward supports lora_type 'lora', 'dvlora' and 'ssb', not {self.lora_type!r}")
         return names
 
     # ---- debug taps for the per-stage parity tests --------------------------------------------

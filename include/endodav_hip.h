@@ -199,11 +199,12 @@ int edv_fold_lora(const float *W_dev, const float *A_dev, const float *B_dev, co
 /* ---- fine-tune step (trainer_end_to_end_video.py:731 forward, :427-431 backward/step) ----
  * edv_set_train(ctx, 1): edv_forward keeps the activations the backward needs (per encoder block: both residual-stream
  * values, the normed MLP input, q|k|v, the attention output and its log-sum-exp, the fc1 pre-activation; per motion module
- * and fusion block: the inputs of their norms and ReLUs).  Supported: VDA head, lora_type none / lora / dvlora, no
- * use_clstoken / residual blocks / temporal_lora / out_sigmoid; anything else is refused with an error.
+ * and fusion block: the inputs of their norms and ReLUs).  Supported: VDA head (disable_conv_head), lora_type none / lora /
+ * dvlora / ssb, with or without temporal_lora; no use_clstoken / residual blocks / out_sigmoid / dash: refused with an error.
  * edv_backward(ctx, disp0, grads): disp0 = the ("disp", 0) map the forward wrote, grads[k] = dL/d("disp", k), k = 0..3
  * (all four required, contiguous fp32).  Leaves the gradient of every LoRA factor of mlp.fc1 / mlp.fc2
- * ("pretrained.blocks.<i>.mlp.fc<j>.lora_{A,B,U,V}", the trainable set of endodav/layers.py:5-34) in context-owned
+ * ("pretrained.blocks.<i>.mlp.fc<j>.lora_{A,B,U,V}") and, with temporal_lora, of ff.net.2 in the motion modules
+ * ("head.motion_modules.<m>...ff.net.2.lora_*") -- the trainable set of endodav/layers.py:5-34 -- in context-owned
  * device memory, fetched with edv_grad(ctx, name, &ptr, &numel).  edv_prepare must run again after the optimizer step. */
 int edv_set_train(edv_ctx *ctx, int32_t on);
 int edv_backward(edv_ctx *ctx, const float *disp0_dev, const float *const grad_disp_dev[4], void *stream);

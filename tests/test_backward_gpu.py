@@ -83,6 +83,26 @@ def test_lora_gradients_match_oracle_autograd(lib, cuda, case):
     print(f"\n[{case}] {len(names)} tensors, worst scale-relative gradient error {worst:.2e}")
 
 
+@pytest.mark.parametrize("temporal", [False, True], ids=["spatial", "spatial+temporal"])
+def test_ssb_gradients(lib, cuda, temporal):
+    """Linear_SSB (lora_A [in,1], lora_B [out,1]), the lora_type of the reference's scripts/train_video.sh, with and without
+    --temporal_lora (ff.net.2 of the four motion modules)."""
+    from tests.golden.cases import VITS_SMALL_HEAD
+
+    kwargs = dict(VITS_SMALL_HEAD, image_shape=(42, 56), lora_type="ssb", disable_conv_head=True, temporal_lora=temporal)
+    model = endodav_amd.endodav(**kwargs, pretrained_path=None)
+    synth.fill_module_(model)
+    names = set_trainable(model, ("lora_A", "lora_B"))
+    assert len(names) == 48 + (8 if temporal else 0)
+    x = torch.from_numpy(synth.synth_clip(1, 3, 42, 56, seed=2, kind="tissue"))
+    model = model.to(cuda).train()
+    gouts = upstream([(3, 1, h, w) for (h, w) in model.output_shapes()])
+    ref, _ = oracle_grads(model, kwargs, x, names, gouts)
+    hip, _ = hip_grads(model, x, names, gouts, cuda)
+    worst = check(hip, ref)
+    print(f"\n[ssb temporal={temporal}] {len(names)} tensors, worst scale-relative gradient error {worst:.2e}")
+
+
 @pytest.mark.parametrize("H,W,T,resize_from", [(224, 280, 2, (256, 320)), (518, 518, 1, None)], ids=["224x280_T2", "518x518_T1"])
 def test_vits_gradients_full_size(lib, cuda, H, W, T, resize_from):
     """ViT-S at the trainer's 256x320 -> (224, 280) geometry (BASELINE config 4) and at 518x518, against the oracle's

@@ -265,6 +265,11 @@ int gemm(const GemmDesc &d, hipStream_t st) {
         return !(e && atoi(e) == 0);
     }();
     if (dma_on && gemm_dma_supported(d) && d.N > 32) return gemm_dma(d, st);
+    static const bool conv_dma_on = [] {
+        const char *e = getenv("EDV_CONV_DMA");  // 0 switches the LDS-DMA convolution off (A/B runs)
+        return !(e && atoi(e) == 0);
+    }();
+    if (conv_dma_on && conv_dma_supported(d)) return conv_dma(d, st);
     switch (pick_tile(d)) {
         case 0: return launch_tile<128, 128, 2, 2, false>(d, st);
         case 1: return launch_tile<128, 64, 2, 2, false>(d, st);

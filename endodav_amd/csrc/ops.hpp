@@ -57,6 +57,9 @@ size_t gemm_workspace();  // floats; enough for any shape on the current device
 // LDS-DMA staged variant (gemm_dma.hip): dense A, K % 32 == 0; picked by gemm() for small/medium grids.
 bool gemm_dma_supported(const GemmDesc &d);
 int gemm_dma(const GemmDesc &d, hipStream_t st);
+// LDS-DMA implicit-GEMM 3x3 convolution (conv_dma.hip): Cin % 32 == 0, any stride the GemmDesc allows
+bool conv_dma_supported(const GemmDesc &d);
+int conv_dma(const GemmDesc &d, hipStream_t st);
 // Split-bf16 variant (gemm_sb.hip): same contract, fp32-equivalent accuracy from six bf16 MFMAs per product.
 bool gemm_sb_supported(const GemmDesc &d);
 int gemm_sb(const GemmDesc &d, hipStream_t st);

@@ -49,6 +49,14 @@ def gemm_sb(M, N, K, act=0, res=False, label=""):
     print(f"gemm_sb {label:10s} M={M:6d} N={N:5d} K={K:5d} act={act} res={int(res)}: {t*1e6:8.1f} us  {2*M*N*K/t/1e12:6.1f} TF-eq (incl. W split)", flush=True)
 
 
+def conv(F, H, W, Cin, Cout, stride=1, pre=0, post=0, label=""):
+    x = torch.randn(F, H, W, Cin, device=dev); w = torch.randn(Cout, 9 * Cin, device=dev) * 0.05; b = torch.randn(Cout, device=dev)
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    y = torch.empty(F, OH, OW, Cout, device=dev)
+    t = timeit(lambda: _lib.check(lib.edv_conv3x3(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), F, H, W, Cin, Cout, stride, pre, post, None, None, st())))
+    print(f"conv {label:12s} F={F} {H}x{W} {Cin}->{Cout} s{stride}: {t*1e6:8.1f} us  {2*F*OH*OW*Cout*9*Cin/t/1e12:6.1f} TF", flush=True)
+
+
 def attn(F, N, heads):
     qkv = torch.randn(F * N, 3 * heads * 64, device=dev)
     o = torch.empty(F * N, heads * 64, device=dev)
@@ -69,6 +77,18 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "sb":
         gemm_sb(M, 384, 1536, res=True, label=f"fc2 T{T}")
     gemm_sb(8192, 8192, 1024, label="8k8k1k")
     gemm_sb(4096, 4096, 4096, label="4096^3")
+elif __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "conv":
+    import os
+    print("EDV_CONV_DMA", os.environ.get("EDV_CONV_DMA"))
+    conv(8, 518, 518, 32, 32, post=1, label="out_conv2.0")
+    conv(8, 296, 296, 64, 32, label="out_conv1")
+    conv(8, 296, 296, 64, 64, pre=1, label="rcu @296")
+    conv(8, 148, 148, 64, 64, pre=1, label="rcu @148")
+    conv(8, 74, 74, 64, 64, pre=1, label="rcu @74")
+    conv(8, 37, 37, 64, 64, pre=1, label="rcu @37")
+    conv(8, 74, 74, 96, 64, label="layer2_rn")
+    conv(8, 37, 37, 192, 64, label="layer3_rn")
+    conv(8, 37, 37, 384, 384, stride=2, label="resize3 s2")
 elif __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "attn":
     import os
     print("EDV_ATTN_PLAIN", os.environ.get("EDV_ATTN_PLAIN"), "EDV_ATTN_KT", os.environ.get("EDV_ATTN_KT"))

@@ -11,6 +11,7 @@
 // In both, X1^T = T1 R1^T (scores) and X2^T = T2 R2^T (dP) land as accumulators whose registers are exactly the B
 // operand of the third product (rows of the streamed tile contract), as in the forward's P V step.
 #include <cmath>
+#include <cstdlib>
 
 #include "ops.hpp"
 
@@ -47,8 +48,9 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float *__restrict
     }
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void attn_spatial_bwd_kernel(const float *__restrict__ qkv, const float *__restrict__ dO, const float *__restrict__ lse,
+// NW waves (32 resident rows each) per workgroup share the streamed tiles
+template <int MODE, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_spatial_bwd_kernel(const float *__restrict__ qkv, const float *__restrict__ dO, const float *__restrict__ lse,
                                                                const float *__restrict__ delta, float *__restrict__ dqkv, int N, int heads) {
     __shared__ __attribute__((aligned(16))) float sT1[TR * TS];
     __shared__ __attribute__((aligned(16))) float sT2[TR * TS];
@@ -57,7 +59,8 @@ __global__ __launch_bounds__(256) void attn_spatial_bwd_kernel(const float *__re
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int nb = (N + 127) / 128;
+    constexpr int RB = NW * 32, NT = NW * 64;
+    const int nb = (N + RB - 1) / RB;
     const int blk = blockIdx.x % nb, fh = blockIdx.x / nb;
     const int head = fh % heads, frame = fh / heads;
     const int D = heads * HD, D3 = 3 * D;
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(256) void attn_spatial_bwd_kernel(const float *__re
     const float *lrow = lse + ((long long)frame * heads + head) * N;
     const float *drow = delta + ((long long)frame * heads + head) * N;
 
-    const int ri = blk * 128 + wave * 32 + l31;  // resident row of this lane (query in MODE_DQ, key in MODE_DKV)
+    const int ri = blk * RB + wave * 32 + l31;  // resident row of this lane (query in MODE_DQ, key in MODE_DKV)
     const int rrow = ri < N ? ri : N - 1;
     const float c1 = 0.125f * 1.44269504088896340736f;  // d^-1/2 * log2(e)
 
@@ -91,14 +94,15 @@ __global__ __launch_bounds__(256) void attn_spatial_bwd_kernel(const float *__re
 #pragma unroll
     for (int r = 0; r < 16; ++r) o0[r] = o1[r] = o2[r] = o3[r] = 0.f;
 
-    // staging: 32 rows x 16 float4 per array = 512 float4 per array; 256 threads -> 2 per array
-    const int sc = tid & 15, sr = tid >> 4;  // chunk, row (0..15); second pass rows +16
-    f32x4 pa[2], pb[2];
+    // staging: 32 rows x 16 float4 per array = 512 float4 per array; NT threads -> SP passes of SR rows
+    constexpr int SR = NT / 16, SP = TR / SR;
+    const int sc = tid & 15, sr = tid >> 4;  // chunk, row within a pass
+    f32x4 pa[SP], pb[SP];
     float pl = 0.f, pd = 0.f;
     auto load_tile = [&](int t0) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            int tr = t0 + sr + 16 * i;
+        for (int i = 0; i < SP; ++i) {
+            int tr = t0 + sr + SR * i;
             tr = tr < N ? tr : N - 1;  // clamped rows are masked below
             if (MODE == MODE_DQ) {
                 const float *p = base + (long long)tr * D3 + sc * 4;
@@ -123,9 +127,9 @@ __global__ __launch_bounds__(256) void attn_spatial_bwd_kernel(const float *__re
         const int t0 = t * TR;
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            *reinterpret_cast<f32x4 *>(&sT1[(sr + 16 * i) * TS + sc * 4]) = pa[i];
-            *reinterpret_cast<f32x4 *>(&sT2[(sr + 16 * i) * TS + sc * 4]) = pb[i];
+        for (int i = 0; i < SP; ++i) {
+            *reinterpret_cast<f32x4 *>(&sT1[(sr + SR * i) * TS + sc * 4]) = pa[i];
+            *reinterpret_cast<f32x4 *>(&sT2[(sr + SR * i) * TS + sc * 4]) = pb[i];
         }
         if (MODE == MODE_DKV && tid < TR) {
             sL[tid] = pl;
@@ -216,11 +220,26 @@ int attn_spatial_bwd(const float *qkv, const float *out, const float *dout, cons
     EDV_CHECK((pairs * 16 + 255) / 256 < (1ll << 31), "grid");
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((pairs * 16 + 255) / 256)), dim3(256), 0, st, dout, out, delta, F, N, heads);
     EDV_LAUNCH_OK();
-    const long long blocks = (long long)F * heads * ((N + 127) / 128);
+    // 4 waves per workgroup share each streamed tile.  2-wave workgroups (a finer grid against the nearly empty last round
+    // of 528 tasks on 512 slots at T=8) measured slower: 1046 vs 967 us at T=8, 3012 vs 2759 us at T=32 (117 TF/s over the
+    // seven products).  EDV_ATTN_BWD_WAVES=2 selects them for A/B runs.
+    static const int forced = [] {
+        const char *e = getenv("EDV_ATTN_BWD_WAVES");
+        return e ? atoi(e) : 0;
+    }();
+    const int nw = forced == 2 ? 2 : 4;
+    const long long blocks = (long long)F * heads * ((N + nw * 32 - 1) / (nw * 32));
     EDV_CHECK(blocks < (1ll << 31), "grid");
-    hipLaunchKernelGGL(attn_spatial_bwd_kernel<MODE_DQ>, dim3((unsigned)blocks), dim3(256), 0, st, qkv, dout, lse, delta, dqkv, N, heads);
-    EDV_LAUNCH_OK();
-    hipLaunchKernelGGL(attn_spatial_bwd_kernel<MODE_DKV>, dim3((unsigned)blocks), dim3(256), 0, st, qkv, dout, lse, delta, dqkv, N, heads);
+    const dim3 grid((unsigned)blocks);
+    if (nw == 4) {
+        hipLaunchKernelGGL((attn_spatial_bwd_kernel<MODE_DQ, 4>), grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, N, heads);
+        EDV_LAUNCH_OK();
+        hipLaunchKernelGGL((attn_spatial_bwd_kernel<MODE_DKV, 4>), grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, N, heads);
+    } else {
+        hipLaunchKernelGGL((attn_spatial_bwd_kernel<MODE_DQ, 2>), grid, dim3(128), 0, st, qkv, dout, lse, delta, dqkv, N, heads);
+        EDV_LAUNCH_OK();
+        hipLaunchKernelGGL((attn_spatial_bwd_kernel<MODE_DKV, 2>), grid, dim3(128), 0, st, qkv, dout, lse, delta, dqkv, N, heads);
+    }
     EDV_LAUNCH_OK();
     return 0;
 }

@@ -15,6 +15,8 @@
 // Measured (profiles/r01_gemm_tile_sweep.txt), with the full epilogue: T=8 qkv 120 -> 111 us, fc2 162 -> 152 us,
 // T=32 qkv 363 -> 340 us (114 TF/s); end to end +2..3 % on ViT-S/B/L.  On bare 8192x8192x1024 the DMA fill rate per CU
 // caps it near 100 TF/s (register staging: 117), a regime the model does not reach with its K <= 4096, N <= 4096.
+#include <cstdio>
+
 #include "gemm_common.hpp"
 
 // Timeline hook for scratch/ubench/gemm_trace.hip; expands to nothing in the product build.
@@ -175,6 +177,7 @@ int dma_slots() {
         if (hipGetDevice(&dev) != hipSuccess) return 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_dma_kernel<STORE, EP>, 256, 0) != hipSuccess) return 0;
+        if (getenv("EDV_DEBUG_SLOTS")) fprintf(stderr, "gemm_dma_kernel<%d,%d>: %d CUs x %d resident workgroups\n", STORE, EP, cus, per_cu);
         return cus * per_cu;
     }();
     return slots;

@@ -104,7 +104,7 @@ elif __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "sweep":
         gemm(M, 384, 384, res=True, label=f"proj T{T}")
         gemm(M, 384, 1536, res=True, label=f"fc2 T{T}")
         attn(T, 1370, 6)
-elif __name__ == "__main__":
+elif __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "attnbwd"):
     M = 8 * 1370
     gemm(M, 1152, 384, label="qkv")
     gemm(M, 1536, 384, act=1, label="fc1+gelu")
@@ -120,3 +120,19 @@ elif __name__ == "__main__":
     attn(32, 1370, 6)
     attn(8, 4096, 6)
     attn(2, 1370, 6)
+
+
+def attn_bwd(F, N, heads):
+    D = heads * 64
+    qkv = torch.randn(F * N, 3 * D, device=dev); o = torch.empty(F * N, D, device=dev); g = torch.randn(F * N, D, device=dev)
+    lse = torch.empty(F * heads * N, device=dev); delta = torch.empty(F * heads * N, device=dev); dq = torch.empty(F * N, 3 * D, device=dev)
+    nb = lib.edv_attn_spatial_workspace(F, N, heads); ws = torch.empty(max(nb // 4, 4), device=dev)
+    _lib.check(lib.edv_attn_spatial(qkv.data_ptr(), o.data_ptr(), F, N, heads, ws.data_ptr(), nb, lse.data_ptr(), st()))
+    t = timeit(lambda: _lib.check(lib.edv_attn_spatial_bwd(qkv.data_ptr(), o.data_ptr(), g.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), F, N, heads, st())))
+    print(f"attn_bwd F={F} N={N} heads={heads}: {t*1e6:8.1f} us  {14*N*N*64*heads*F/t/1e12:6.1f} TF (7 products)", flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "attnbwd":
+    import os
+    print("EDV_ATTN_BWD_WAVES", os.environ.get("EDV_ATTN_BWD_WAVES"))
+    attn_bwd(8, 1370, 6); attn_bwd(32, 1370, 6); attn_bwd(16, 1370, 12); attn_bwd(16, 321, 12)

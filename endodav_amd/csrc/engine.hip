@@ -655,9 +655,10 @@ struct Run {
         }
         float *attws = nullptr;
         if (attws_each) EDV_TRY(wsbuf("attws", attws_each * nstreams, &attws));
-        // Stream-K for the dense GEMMs is opt-in (EDV_GEMM_STREAMK=1): with 4-5 co-resident 64x64-tile workgroups per CU
-        // the statically assigned persistent form measured SLOWER than the plain grid (qkv T=8 122 vs 109 us) because
-        // the SIMD issues oldest-wave-first and the young workgroups of a CU starve (profiles/r01_gemm_tile_sweep.txt).
+        // Stream-K for the dense GEMMs is opt-in (EDV_GEMM_STREAMK=1): with four co-resident 64x64-tile workgroups per CU
+        // the statically assigned persistent form measures neutral against the plain grid (qkv T=8 113.7 vs 109.9 us,
+        // fc2 147.0 vs 151.5): the SIMD issues oldest-wave-first, the workgroups of a CU run at very different speeds, and
+        // what the split saves on the tail is lost in balance (profiles/r01_gemm_tile_sweep.txt).
         static const bool gemm_streamk = [] {
             const char *e = getenv("EDV_GEMM_STREAMK");
             return e && atoi(e) != 0;

@@ -177,6 +177,11 @@ int dma_slots() {
         if (hipGetDevice(&dev) != hipSuccess) return 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_dma_kernel<STORE, EP>, 256, 0) != hipSuccess) return 0;
+        // The occupancy API answers 5 (5 x 32 KB = the whole 160 KB of LDS), the hardware places 4: the timeline of
+        // scratch/ubench/gemm_trace.hip shows exactly 4 x 256 workgroups alive.  A persistent grid must match what is really
+        // resident, or the surplus workgroups start only when others finish.  EDV_GEMM_SLOTS_PER_CU overrides.
+        if (per_cu > 4) per_cu = 4;
+        if (const char *e = getenv("EDV_GEMM_SLOTS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
         if (getenv("EDV_DEBUG_SLOTS")) fprintf(stderr, "gemm_dma_kernel<%d,%d>: %d CUs x %d resident workgroups\n", STORE, EP, cus, per_cu);
         return cus * per_cu;
     }();

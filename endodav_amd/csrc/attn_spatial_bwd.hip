@@ -95,14 +95,16 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_bwd_kernel(const float *
     for (int r = 0; r < 16; ++r) o0[r] = o1[r] = o2[r] = o3[r] = 0.f;
 
     // staging: 32 rows x 16 float4 per array = 512 float4 per array; NT threads -> SP passes of SR rows
-    constexpr int SR = NT / 16, SP = TR / SR;
-    const int sc = tid & 15, sr = tid >> 4;  // chunk, row within a pass
+    constexpr int SLOTS = TR * 16, SP = (SLOTS + NT - 1) / NT;  // float4 slots per array, passes (slot = tid + NT * pass)
     f32x4 pa[SP], pb[SP];
     float pl = 0.f, pd = 0.f;
     auto load_tile = [&](int t0) {
 #pragma unroll
         for (int i = 0; i < SP; ++i) {
-            int tr = t0 + sr + SR * i;
+            const int slot = tid + NT * i;
+            if (SLOTS % NT != 0 && slot >= SLOTS) break;
+            const int sc = slot & 15;
+            int tr = t0 + (slot >> 4);
             tr = tr < N ? tr : N - 1;  // clamped rows are masked below
             if (MODE == MODE_DQ) {
                 const float *p = base + (long long)tr * D3 + sc * 4;
@@ -128,8 +130,10 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_bwd_kernel(const float *
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < SP; ++i) {
-            *reinterpret_cast<f32x4 *>(&sT1[(sr + SR * i) * TS + sc * 4]) = pa[i];
-            *reinterpret_cast<f32x4 *>(&sT2[(sr + SR * i) * TS + sc * 4]) = pb[i];
+            const int slot = tid + NT * i;
+            if (SLOTS % NT != 0 && slot >= SLOTS) break;
+            *reinterpret_cast<f32x4 *>(&sT1[(slot >> 4) * TS + (slot & 15) * 4]) = pa[i];
+            *reinterpret_cast<f32x4 *>(&sT2[(slot >> 4) * TS + (slot & 15) * 4]) = pb[i];
         }
         if (MODE == MODE_DKV && tid < TR) {
             sL[tid] = pl;
@@ -227,7 +231,7 @@ int attn_spatial_bwd(const float *qkv, const float *out, const float *dout, cons
         const char *e = getenv("EDV_ATTN_BWD_WAVES");
         return e ? atoi(e) : 0;
     }();
-    const int nw = forced == 2 ? 2 : 4;
+    const int nw = forced == 2 ? 2 : (forced == 3 ? 3 : 4);
     const long long blocks = (long long)F * heads * ((N + nw * 32 - 1) / (nw * 32));
     EDV_CHECK(blocks < (1ll << 31), "grid");
     const dim3 grid((unsigned)blocks);
@@ -235,6 +239,10 @@ int attn_spatial_bwd(const float *qkv, const float *out, const float *dout, cons
         hipLaunchKernelGGL((attn_spatial_bwd_kernel<MODE_DQ, 4>), grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, N, heads);
         EDV_LAUNCH_OK();
         hipLaunchKernelGGL((attn_spatial_bwd_kernel<MODE_DKV, 4>), grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, N, heads);
+    } else if (nw == 3) {
+        hipLaunchKernelGGL((attn_spatial_bwd_kernel<MODE_DQ, 3>), grid, dim3(192), 0, st, qkv, dout, lse, delta, dqkv, N, heads);
+        EDV_LAUNCH_OK();
+        hipLaunchKernelGGL((attn_spatial_bwd_kernel<MODE_DKV, 3>), grid, dim3(192), 0, st, qkv, dout, lse, delta, dqkv, N, heads);
     } else {
         hipLaunchKernelGGL((attn_spatial_bwd_kernel<MODE_DQ, 2>), grid, dim3(128), 0, st, qkv, dout, lse, delta, dqkv, N, heads);
         EDV_LAUNCH_OK();

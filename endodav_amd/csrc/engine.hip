@@ -64,6 +64,8 @@ struct edv_ctx {
     bool train = false;           // forward keeps the activations the backward needs (edv_set_train)
     bool train_prepared = false;  // transposed / flipped weights of the input-gradient GEMMs are current
     bool have_saved = false;      // a training forward has run since the last backward
+    bool grad_encoder = true;     // which factor gradients the caller wants (edv_set_grad_scope): the trainer alternates
+    bool grad_temporal = true;    // spatial and temporal tuning phases (trainer_end_to_end_video.py:327-339)
     std::unordered_map<std::string, Buf> grads;  // gradients of the trainable parameters, owned
     int launches = 0;
     size_t bytes = 0;
@@ -982,7 +984,7 @@ struct Run {
         EDV_TRY(saved(tg + "qkv1", &qkvs[1]));
         EDV_TRY(saved(tg + "ff1", &ff1));
         EDV_TRY(dgemm(d, M, C, p + ".proj_out", C, dh));                   // x = xin + proj_out(h3)
-        if (cfg.temporal_lora && cfg.lora_type != EDV_LORA_NONE) {        // temporal LoRA on ff.net.2 (endodav.py:119-137)
+        if (cfg.temporal_lora && cfg.lora_type != EDV_LORA_NONE && c->grad_temporal) {  // temporal LoRA on ff.net.2 (endodav.py:119-137)
             const float *ff2;
             EDV_TRY(saved(tg + "ff2", &ff2));
             EDV_TRY(lora_step(tb + ".ff.net.2", ff2, 4 * C, dh, C, M, cfg.lora_rank, cfg.lora_type == EDV_LORA_LORA ? 2.0f : 1.0f, "", lora_ws, lora_ws_n));
@@ -1117,6 +1119,10 @@ struct Run {
         }
         EDV_TRY(motion_module_bwd(0, d_l[3], h3 * w3, oc[2]));
         EDV_TRY(motion_module_bwd(1, d_l[4], h4 * w4, oc[3]));
+        if (!c->grad_encoder || cfg.lora_type == EDV_LORA_NONE) {  // temporal-only phase: nothing trainable below the head
+            c->have_saved = false;
+            return 0;
+        }
         {
             int mx = oc[0];
             for (int j = 1; j < 4; ++j) mx = oc[j] > mx ? oc[j] : mx;
@@ -1352,6 +1358,13 @@ int edv_set_train(edv_ctx *ctx, int32_t on) {
     EDV_CHECK(ctx, "null context");
     ctx->train = on != 0;
     if (!ctx->train) ctx->have_saved = false;
+    return 0;
+}
+
+int edv_set_grad_scope(edv_ctx *ctx, int32_t encoder_factors, int32_t temporal_factors) {
+    EDV_CHECK(ctx, "null context");
+    ctx->grad_encoder = encoder_factors != 0;
+    ctx->grad_temporal = temporal_factors != 0;
     return 0;
 }
 

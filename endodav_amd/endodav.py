@@ -362,6 +362,9 @@ class _EdvFunction(torch.autograd.Function):
             gs = [(g.detach().contiguous().float() if g is not None else torch.zeros(shp, device=ctx.device)) for g, shp in zip(gouts, ctx.shapes)]
             ptrs = (C.c_void_p * 4)(*[g.data_ptr() for g in gs])
             stream = C.c_void_p(_lib.stream_ptr(ctx.device))
+            enc = any(".mlp.fc" in n for n in ctx.names)
+            tmp = any(".ff.net.2." in n for n in ctx.names)
+            _lib.check(lib.edv_set_grad_scope(C.c_void_p(ctx.handle), int(enc), int(tmp)), "edv_set_grad_scope")
             _lib.check(lib.edv_backward(C.c_void_p(ctx.handle), disp0.data_ptr(), ptrs, stream), "edv_backward")
             grads = []
             for name, shp in zip(ctx.names, ctx.param_shapes):

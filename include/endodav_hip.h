@@ -207,6 +207,10 @@ int edv_fold_lora(const float *W_dev, const float *A_dev, const float *B_dev, co
  * ("head.motion_modules.<m>...ff.net.2.lora_*") -- the trainable set of endodav/layers.py:5-34 -- in context-owned
  * device memory, fetched with edv_grad(ctx, name, &ptr, &numel).  edv_prepare must run again after the optimizer step. */
 int edv_set_train(edv_ctx *ctx, int32_t on);
+/* Which factor gradients the next edv_backward has to produce.  The trainer alternates spatial and temporal tuning phases
+ * (trainer_end_to_end_video.py:327-339); with encoder_factors = 0 the backward stops at the head (nothing below it is
+ * trainable), with temporal_factors = 0 the ff.net.2 products are skipped.  Default: both. */
+int edv_set_grad_scope(edv_ctx *ctx, int32_t encoder_factors, int32_t temporal_factors);
 int edv_backward(edv_ctx *ctx, const float *disp0_dev, const float *const grad_disp_dev[4], void *stream);
 int edv_grad(edv_ctx *ctx, const char *name, float **grad_dev, int64_t *numel);
 int edv_grad_copy(edv_ctx *ctx, const char *name, float *dst_dev, int64_t numel, void *stream); /* stream-ordered copy into caller memory */

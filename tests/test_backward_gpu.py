@@ -160,6 +160,26 @@ def test_freeze_schedule_selects_the_gradient_set(lib, cuda):
                 assert p.grad is None, n
 
 
+def test_temporal_only_phase_stops_at_the_head(lib, cuda):
+    """The trainer's temporal tuning phase (trainer_end_to_end_video.py:327-339): only ff.net.2 factors are trainable, the
+    backward does not enter the encoder, and the gradients equal those of a full backward."""
+    model, kwargs, shape, kind, _ = build_model("micro_vda_temporal_lora")
+    x = case_input("micro_vda_temporal_lora")
+    model = model.to(cuda).train()
+    gouts = upstream([(shape[0] * shape[1], 1, h, w) for (h, w) in model.output_shapes()])
+    all_names = set_trainable(model, FACTORS)
+    full, _ = hip_grads(model, x, all_names, gouts, cuda)
+    full = {n: g.clone() for n, g in full.items()}
+    n_full = model.launch_count()
+    t_names = [n for n in all_names if ".ff.net.2." in n]
+    for n, p in model.named_parameters():
+        p.requires_grad = n in t_names
+    part, _ = hip_grads(model, x, t_names, gouts, cuda)
+    assert model.launch_count() < n_full  # the encoder backward did not run
+    for n in t_names:
+        assert torch.equal(part[n], full[n]), n
+
+
 def test_optimizer_step_is_seen_by_the_next_forward(lib, cuda):
     model, kwargs, shape, kind, _ = build_model("micro_vda_lora_b2")
     x = case_input("micro_vda_lora_b2").to(cuda)

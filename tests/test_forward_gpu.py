@@ -186,6 +186,19 @@ def test_weights_update_is_seen(cuda):
     assert (out1[("disp", 0)] - out0[("disp", 0)]).abs().max() > 0
 
 
+def test_survives_dataparallel_wrapper(cuda):
+    """The trainer wraps the depth model in nn.DataParallel (trainer_end_to_end_video.py:269-271, --use_dp) and still
+    reaches .module.state_dict() / infer through it; with one visible device the wrapper calls the module directly."""
+    model, kwargs, x, out = run_hip("micro_vda_dvlora", cuda)
+    dp = torch.nn.DataParallel(model)
+    with torch.no_grad():
+        out_dp = dp(x)
+    assert set(out_dp) == {("disp", s) for s in range(4)}
+    for s in range(4):
+        assert torch.equal(out_dp[("disp", s)], out[("disp", s)])
+    assert set(dp.module.state_dict()) == set(model.state_dict())
+
+
 def test_errors_are_loud(cuda):
     import endodav_amd
 

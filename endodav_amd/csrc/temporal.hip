@@ -3,6 +3,8 @@
 //   frames; attention.py:182-211: softmax(q kᵀ * d^-0.5) v with 8 heads; attention.py:363-384: GEGLU.
 // The regrouping is never materialised: the fused q|k|v rows stay in the channels-last token order
 // [(b*T + t)*P + p, 3C] and the frame axis is reached by address stride P*3C.
+#include <cstdlib>
+
 #include "ops.hpp"
 
 namespace edv {
@@ -68,6 +70,134 @@ __global__ __launch_bounds__(256) void attn_temporal_kernel(const float *__restr
     }
 }
 
+// T <= 8: one thread per (clip, pixel, head) computes ALL T queries, so every q / k / v element is read from memory once
+// (the per-query kernel above re-reads each K/V row T times through L1/L2: 51 us per call at T=8, 7.7x the HBM time of the
+// tensors).  Scores live in T x T registers; two sweeps over the head dimension in float4 steps.
+template <int TT>
+__global__ __launch_bounds__(256) void attn_temporal_small_kernel(const float *__restrict__ qkv, float *__restrict__ out, int B, int T, int P, int C, int heads,
+                                                                   float scale) {
+    const long long total = (long long)B * P * heads;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (gid >= total) return;
+    const int head = (int)(gid % heads);
+    long long r = gid / heads;
+    const int p = (int)(r % P);
+    const int b = (int)(r / P);
+    const int d = C / heads, C3 = 3 * C;
+    const long long ts3 = (long long)P * C3, ts1 = (long long)P * C;
+    const float *qb = qkv + ((long long)(b * T) * P + p) * C3 + head * d;
+    const float *kb = qb + C, *vb = qb + 2 * C;
+    float *ob = out + ((long long)(b * T) * P + p) * C + head * d;
+    float S[TT][TT];
+#pragma unroll
+    for (int i = 0; i < TT; ++i)
+#pragma unroll
+        for (int j = 0; j < TT; ++j) S[i][j] = 0.f;
+#pragma unroll 2
+    for (int c = 0; c < d; c += 4) {
+        f32x4 q4[TT], k4[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) {
+            const int tc = t < T ? t : T - 1;
+            q4[t] = *reinterpret_cast<const f32x4 *>(qb + tc * ts3 + c);
+            k4[t] = *reinterpret_cast<const f32x4 *>(kb + tc * ts3 + c);
+        }
+#pragma unroll
+        for (int i = 0; i < TT; ++i)
+#pragma unroll
+            for (int j = 0; j < TT; ++j) S[i][j] += (q4[i].x * k4[j].x + q4[i].y * k4[j].y) + (q4[i].z * k4[j].z + q4[i].w * k4[j].w);
+    }
+#pragma unroll
+    for (int i = 0; i < TT; ++i) {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < TT; ++j)
+            if (j < T) {
+                S[i][j] *= scale;
+                mx = fmaxf(mx, S[i][j]);
+            }
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+            S[i][j] = j < T ? expf(S[i][j] - mx) : 0.f;
+            sum += S[i][j];
+        }
+        const float inv = 1.0f / sum;
+#pragma unroll
+        for (int j = 0; j < TT; ++j) S[i][j] *= inv;
+    }
+#pragma unroll 2
+    for (int c = 0; c < d; c += 4) {
+        f32x4 v4[TT];
+#pragma unroll
+        for (int t = 0; t < TT; ++t) v4[t] = *reinterpret_cast<const f32x4 *>(vb + (t < T ? t : T - 1) * ts3 + c);
+#pragma unroll
+        for (int i = 0; i < TT; ++i) {
+            if (i < T) {
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < TT; ++j) acc += S[i][j] * v4[j];
+                *reinterpret_cast<f32x4 *>(ob + i * ts1 + c) = acc;
+            }
+        }
+    }
+}
+
+// Wide channels (d = C/8 >= 24) at T <= 8: one 64-thread workgroup per (clip, pixel).  The pixel's T rows of q|k|v
+// (T * 3C floats, <= 36 KB at C = 384) are fetched with ONE round of coalesced loads into LDS; thread (query tq, head) then
+// works out of LDS.  The per-thread kernels above chain 24 dependent load batches per thread when d = 48 and there are only
+// B * P * 8 = 2888 threads to hide them behind (50 us per call for 18 MB of traffic).
+__global__ __launch_bounds__(64) void attn_temporal_pixel_kernel(const float *__restrict__ qkv, float *__restrict__ out, int T, int P, int C, int heads,
+                                                                  float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [T][3C]
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / P, p = blockIdx.x - b * P;
+    const int C3 = 3 * C, n4 = C3 >> 2;
+    for (int idx = tid; idx < T * n4; idx += 64) {
+        const int t = idx / n4, c4 = idx - t * n4;
+        *reinterpret_cast<f32x4 *>(&sm[t * C3 + 4 * c4]) = *reinterpret_cast<const f32x4 *>(qkv + ((long long)(b * T + t) * P + p) * C3 + 4 * c4);
+    }
+    __syncthreads();
+    const int head = tid % heads, tq = tid / heads;
+    if (tq >= T) return;
+    const int d = C / heads;
+    const float *q = sm + tq * C3 + head * d;
+    float s[8];
+#pragma unroll
+    for (int ts = 0; ts < 8; ++ts) s[ts] = 0.f;
+    for (int c = 0; c < d; c += 4) {
+        const f32x4 q4 = *reinterpret_cast<const f32x4 *>(q + c);
+#pragma unroll
+        for (int ts = 0; ts < 8; ++ts)
+            if (ts < T) {
+                const f32x4 k4 = *reinterpret_cast<const f32x4 *>(sm + ts * C3 + C + head * d + c);
+                s[ts] += (q4.x * k4.x + q4.y * k4.y) + (q4.z * k4.z + q4.w * k4.w);
+            }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int ts = 0; ts < 8; ++ts)
+        if (ts < T) {
+            s[ts] *= scale;
+            mx = fmaxf(mx, s[ts]);
+        }
+    float sum = 0.f;
+#pragma unroll
+    for (int ts = 0; ts < 8; ++ts) {
+        s[ts] = ts < T ? expf(s[ts] - mx) : 0.f;
+        sum += s[ts];
+    }
+    const float inv = 1.0f / sum;
+    float *op = out + ((long long)(b * T + tq) * P + p) * C + head * d;
+    for (int c = 0; c < d; c += 4) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ts = 0; ts < 8; ++ts)
+            if (ts < T) acc += s[ts] * *reinterpret_cast<const f32x4 *>(sm + ts * C3 + 2 * C + head * d + c);
+        *reinterpret_cast<f32x4 *>(op + c) = acc * inv;
+    }
+}
+
 __global__ __launch_bounds__(256) void geglu_kernel(const float *__restrict__ x, float *__restrict__ y, long long total4, int inner4) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
         const long long m = i / inner4;
@@ -92,7 +222,21 @@ int attn_temporal(const float *qkv, float *out, int B, int T, int P, int C, int 
     EDV_CHECK(blocks < (1ll << 31), "grid");
     const float scale = 1.0f / sqrtf((float)(C / heads));
     dim3 grid((unsigned)blocks), block(256);
-    if (T <= 8)
+    static const bool per_query = [] {
+        const char *e = getenv("EDV_TATTN_PER_QUERY");  // 1: the one-thread-per-query kernel also for T <= 8 (A/B runs)
+        return e && atoi(e) != 0;
+    }();
+    if (T <= 8 && !per_query && heads == 8 && C / heads >= 24 && (size_t)T * 3 * C * sizeof(float) <= 64 * 1024 && (long long)B * P < (1ll << 31)) {
+        hipLaunchKernelGGL(attn_temporal_pixel_kernel, dim3((unsigned)(B * P)), dim3(64), (size_t)T * 3 * C * sizeof(float), st, qkv, out, T, P, C, heads,
+                           scale);
+    } else if (T <= 8 && !per_query) {
+        const long long tot = (long long)B * P * heads;
+        const dim3 g2((unsigned)((tot + 255) / 256));
+        if (T <= 4)
+            hipLaunchKernelGGL(attn_temporal_small_kernel<4>, g2, block, 0, st, qkv, out, B, T, P, C, heads, scale);
+        else
+            hipLaunchKernelGGL(attn_temporal_small_kernel<8>, g2, block, 0, st, qkv, out, B, T, P, C, heads, scale);
+    } else if (T <= 8)
         hipLaunchKernelGGL(attn_temporal_kernel<8>, grid, block, 0, st, qkv, out, B, T, P, C, heads, scale);
     else if (T <= 16)
         hipLaunchKernelGGL(attn_temporal_kernel<16>, grid, block, 0, st, qkv, out, B, T, P, C, heads, scale);

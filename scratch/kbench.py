@@ -104,7 +104,7 @@ elif __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "sweep":
         gemm(M, 384, 384, res=True, label=f"proj T{T}")
         gemm(M, 384, 1536, res=True, label=f"fc2 T{T}")
         attn(T, 1370, 6)
-elif __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] == "attnbwd"):
+elif __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("attnbwd", "tattn")):
     M = 8 * 1370
     gemm(M, 1152, 384, label="qkv")
     gemm(M, 1536, 384, act=1, label="fc1+gelu")
@@ -136,3 +136,15 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "attnbwd":
     import os
     print("EDV_ATTN_BWD_WAVES", os.environ.get("EDV_ATTN_BWD_WAVES"))
     attn_bwd(8, 1370, 6); attn_bwd(32, 1370, 6); attn_bwd(16, 1370, 12); attn_bwd(16, 321, 12)
+
+
+def tattn(B, T, P, C):
+    qkv = torch.randn(B * T * P, 3 * C, device=dev); o = torch.empty(B * T * P, C, device=dev)
+    t = timeit(lambda: _lib.check(lib.edv_attn_temporal(qkv.data_ptr(), o.data_ptr(), B, T, P, C, 8, st())))
+    print(f"attn_temporal B={B} T={T} P={P} C={C}: {t*1e6:8.1f} us  {(qkv.numel()+o.numel())*4/t/1e12:5.2f} TB/s", flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "tattn":
+    import os
+    print("EDV_TATTN_PER_QUERY", os.environ.get("EDV_TATTN_PER_QUERY"))
+    tattn(1, 8, 1369, 192); tattn(1, 8, 361, 384); tattn(1, 8, 1369, 64); tattn(1, 8, 5476, 64); tattn(1, 4, 5476, 64)

@@ -2,6 +2,8 @@
 // the fine-tune step trains only the LoRA factors (endodav/layers.py:5-34), so every frozen
 // operator needs its input gradient and nothing else.  Layouts are the forward's: channels-last activations, fused
 // q|k|v rows, rows = (frame, token).  Each kernel cites the forward it differentiates.
+#include <cstdlib>
+
 #include "ops.hpp"
 
 // The bilinear adjoint must reproduce the forward's interpolation weights: ATen computes the source coordinate as a
@@ -461,6 +463,102 @@ __global__ __launch_bounds__(64) void attn_temporal_bwd_kernel(const float *__re
     }
 }
 
+// T <= 8, 8 heads: one 64-thread workgroup per (clip, pixel), everything out of LDS (the forward's attn_temporal_pixel_kernel).
+// The pixel's T rows of q|k|v and of dO are fetched with one round of coalesced loads; thread (t, head) first acts as query
+// t (scores, P, dS, dQ), publishes its P and dS rows, then acts as key t (dK = sum_q dS[q][t] Q[q], dV = sum_q P[q][t] dO[q]).
+__global__ __launch_bounds__(64) void attn_temporal_bwd_pixel_kernel(const float *__restrict__ qkv, const float *__restrict__ dout, float *__restrict__ dqkv,
+                                                                      int T, int P, int C, int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [T][3C] q|k|v, [T][C] dO, [heads][T][8] P, [heads][T][8] dS
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / P, p = blockIdx.x - b * P;
+    const int C3 = 3 * C, n3 = C3 >> 2, n1 = C >> 2;
+    float *sG = sm + T * C3, *sP = sG + T * C, *sS = sP + heads * T * 8;
+    for (int idx = tid; idx < T * n3; idx += 64) {
+        const int t = idx / n3, c4 = idx - t * n3;
+        *reinterpret_cast<f32x4 *>(&sm[t * C3 + 4 * c4]) = *reinterpret_cast<const f32x4 *>(qkv + ((long long)(b * T + t) * P + p) * C3 + 4 * c4);
+    }
+    for (int idx = tid; idx < T * n1; idx += 64) {
+        const int t = idx / n1, c4 = idx - t * n1;
+        *reinterpret_cast<f32x4 *>(&sG[t * C + 4 * c4]) = *reinterpret_cast<const f32x4 *>(dout + ((long long)(b * T + t) * P + p) * C + 4 * c4);
+    }
+    __syncthreads();
+    const int head = tid % heads, t = tid / heads;
+    const int d = C / heads;
+    const bool live = t < T;
+    const int tc = live ? t : T - 1;
+    const float *q = sm + tc * C3 + head * d, *g = sG + tc * C + head * d;
+    float s[8], dp[8];
+#pragma unroll
+    for (int ts = 0; ts < 8; ++ts) s[ts] = dp[ts] = 0.f;
+    for (int c = 0; c < d; c += 4) {
+        const f32x4 q4 = *reinterpret_cast<const f32x4 *>(q + c), g4 = *reinterpret_cast<const f32x4 *>(g + c);
+#pragma unroll
+        for (int ts = 0; ts < 8; ++ts)
+            if (ts < T) {
+                const f32x4 k4 = *reinterpret_cast<const f32x4 *>(sm + ts * C3 + C + head * d + c);
+                const f32x4 v4 = *reinterpret_cast<const f32x4 *>(sm + ts * C3 + 2 * C + head * d + c);
+                s[ts] += (q4.x * k4.x + q4.y * k4.y) + (q4.z * k4.z + q4.w * k4.w);
+                dp[ts] += (g4.x * v4.x + g4.y * v4.y) + (g4.z * v4.z + g4.w * v4.w);
+            }
+    }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int ts = 0; ts < 8; ++ts)
+        if (ts < T) {
+            s[ts] *= scale;
+            mx = fmaxf(mx, s[ts]);
+        }
+    float sum = 0.f;
+#pragma unroll
+    for (int ts = 0; ts < 8; ++ts) {
+        s[ts] = ts < T ? expf(s[ts] - mx) : 0.f;
+        sum += s[ts];
+    }
+    const float inv = 1.0f / sum;
+    float dot = 0.f;
+#pragma unroll
+    for (int ts = 0; ts < 8; ++ts) {
+        s[ts] *= inv;  // P
+        dot += s[ts] * dp[ts];
+    }
+#pragma unroll
+    for (int ts = 0; ts < 8; ++ts) {
+        dp[ts] = s[ts] * (dp[ts] - dot) * scale;  // dS * scale (zero for ts >= T)
+        if (live) {  // threads with t >= T only keep the barrier company
+            sP[(head * T + t) * 8 + ts] = s[ts];
+            sS[(head * T + t) * 8 + ts] = dp[ts];
+        }
+    }
+    float *orow = dqkv + ((long long)(b * T + tc) * P + p) * C3 + head * d;
+    if (live)
+        for (int c = 0; c < d; c += 4) {  // dQ[t] = sum_ts dS[t][ts] K[ts]
+            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ts = 0; ts < 8; ++ts)
+                if (ts < T) acc += dp[ts] * *reinterpret_cast<const f32x4 *>(sm + ts * C3 + C + head * d + c);
+            *reinterpret_cast<f32x4 *>(orow + c) = acc;
+        }
+    __syncthreads();
+    if (!live) return;
+    float ps[8], ds[8];  // column t of P and dS: over the queries
+#pragma unroll
+    for (int tq = 0; tq < 8; ++tq) {
+        ps[tq] = tq < T ? sP[(head * T + tq) * 8 + t] : 0.f;
+        ds[tq] = tq < T ? sS[(head * T + tq) * 8 + t] : 0.f;
+    }
+    for (int c = 0; c < d; c += 4) {
+        f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tq = 0; tq < 8; ++tq)
+            if (tq < T) {
+                dk += ds[tq] * *reinterpret_cast<const f32x4 *>(sm + tq * C3 + head * d + c);
+                dv += ps[tq] * *reinterpret_cast<const f32x4 *>(sG + tq * C + head * d + c);
+            }
+        *reinterpret_cast<f32x4 *>(orow + C + c) = dk;
+        *reinterpret_cast<f32x4 *>(orow + 2 * C + c) = dv;
+    }
+}
+
 // zero insertion of a stride-2 convolution's output gradient: z[f, 2*oy, 2*ox, :] = dy[f, oy, ox, :], zero elsewhere; the
 // stride-2 input gradient is then the stride-1 input-gradient convolution of z (flipped taps)
 __global__ __launch_bounds__(256) void dilate2_kernel(const float *__restrict__ dy, float *__restrict__ z, int F, int H, int W, int C, int OH, int OW) {
@@ -757,7 +855,14 @@ int attn_temporal_bwd(const float *qkv, const float *dout, float *dqkv, int B, i
     EDV_CHECK(blocks < (1ll << 31), "grid");
     const float scale = 1.0f / sqrtf((float)(C / heads));
     dim3 grid((unsigned)blocks), block(64);
-    if (T <= 8)
+    const size_t lds = ((size_t)T * 4 * C + (size_t)2 * heads * T * 8) * sizeof(float);
+    static const bool per_thread = [] {
+        const char *e = getenv("EDV_TATTN_BWD_PER_THREAD");  // 1: the one-thread-per-(pixel, head) kernel also for T <= 8 (A/B runs)
+        return e && atoi(e) != 0;
+    }();
+    if (T <= 8 && heads == 8 && lds <= 64 * 1024 && (long long)B * P < (1ll << 31) && !per_thread)
+        hipLaunchKernelGGL(attn_temporal_bwd_pixel_kernel, dim3((unsigned)(B * P)), dim3(64), lds, st, qkv, dout, dqkv, T, P, C, heads, scale);
+    else if (T <= 8)
         hipLaunchKernelGGL(attn_temporal_bwd_kernel<8>, grid, block, 0, st, qkv, dout, dqkv, B, T, P, C, heads, scale);
     else if (T <= 16)
         hipLaunchKernelGGL(attn_temporal_bwd_kernel<16>, grid, block, 0, st, qkv, dout, dqkv, B, T, P, C, heads, scale);

@@ -217,7 +217,8 @@ def test_groupnorm_bwd(lib, cuda, Fr, P, Cc, acc):
     close(dx, ref + (base.double() if acc else 0), 5e-6, "groupnorm_bwd")
 
 
-@pytest.mark.parametrize("Bc,T,P,Cc", [(1, 8, 300, 192), (2, 3, 50, 64), (1, 16, 61, 384), (1, 32, 41, 32), (1, 1, 9, 64)])
+@pytest.mark.parametrize("Bc,T,P,Cc", [(1, 8, 300, 192), (2, 3, 50, 64), (1, 16, 61, 384), (1, 32, 41, 32), (1, 1, 9, 64), (1, 8, 361, 384), (2, 5, 77, 64),
+                                       (1, 8, 1500, 64)])
 def test_attn_temporal_bwd(lib, cuda, Bc, T, P, Cc):
     heads, d = 8, Cc // 8
     rows = Bc * T * P

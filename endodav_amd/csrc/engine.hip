@@ -355,10 +355,12 @@ struct Run {
         float *gn, *h, *hn, *qkv3, *att, *ff1, *ff2, *stats;
         // training keeps: the module input, the GroupNorm statistics, h before each of its three residual updates,
         // both q|k|v and the GEGLU input (names tagged with the module index); inference reuses one set of buffers
-        const std::string tg = c->train ? "mm" + std::to_string(m) + "." : "mm.";
+        // scratch that nobody reads later comes in two sets: "mmb." for module 1, which may run beside module 0 on another stream
+        const std::string sc_ = m == 1 ? "mmb." : "mm.";
+        const std::string tg = c->train ? "mm" + std::to_string(m) + "." : sc_;
         float *hs[4];  // h after proj_in, after attention 0, after attention 1, after the feed-forward
         const float *xin = x;
-        EDV_TRY(wsbuf("mm.gn", (size_t)M * C, &gn));
+        EDV_TRY(wsbuf(sc_ + "gn", (size_t)M * C, &gn));
         EDV_TRY(wsbuf(tg + "h", (size_t)M * C, &h));
         hs[0] = hs[1] = hs[2] = hs[3] = h;
         if (c->train) {
@@ -368,10 +370,10 @@ struct Run {
             xin = xc;
             for (int k = 1; k < 4; ++k) EDV_TRY(wsbuf(tg + "h" + std::to_string(k), (size_t)M * C, &hs[k]));
         }
-        EDV_TRY(wsbuf("mm.hn", (size_t)M * C, &hn));
-        EDV_TRY(wsbuf("mm.att", (size_t)M * C, &att));
+        EDV_TRY(wsbuf(sc_ + "hn", (size_t)M * C, &hn));
+        EDV_TRY(wsbuf(sc_ + "att", (size_t)M * C, &att));
         EDV_TRY(wsbuf(tg + "ff1", (size_t)M * 8 * C, &ff1));
-        EDV_TRY(wsbuf(c->train ? tg + "ff2" : std::string("mm.ff2"), (size_t)M * 4 * C, &ff2));  // input of ff.net.2: its LoRA gradient needs it
+        EDV_TRY(wsbuf(c->train ? tg + "ff2" : sc_ + "ff2", (size_t)M * 4 * C, &ff2));  // input of ff.net.2: its LoRA gradient needs it
         EDV_TRY(wsbuf(tg + "stats", (size_t)F * 32 * 2, &stats));
         const float *w, *b;
         EDV_TRY(param(p + ".norm.weight", &w));
@@ -385,7 +387,7 @@ struct Run {
             const std::string ab = tb + ".attention_blocks." + std::to_string(a);
             const float *pe;
             EDV_TRY(param(ab + ".pos_encoder.pe", &pe));
-            EDV_TRY(wsbuf(c->train ? tg + "qkv" + std::to_string(a) : std::string("mm.qkv"), (size_t)M * 3 * C, &qkv3));
+            EDV_TRY(wsbuf(c->train ? tg + "qkv" + std::to_string(a) : sc_ + "qkv", (size_t)M * 3 * C, &qkv3));
             EDV_TRY(ln(hs[a], identity_map(), tb + ".norms." + std::to_string(a), hn, M, C, 1e-5f, pe, P, T));
             const float *wqkv;
             EDV_TRY(packedw(ab + ".qkv", &wqkv));
@@ -701,17 +703,21 @@ struct Run {
         EDV_TRY(wsbuf("l2", (size_t)F * h2 * w2 * oc[1], &l2));
         EDV_TRY(wsbuf("l3", (size_t)F * h3 * w3 * oc[2], &l3));
         EDV_TRY(wsbuf("l4", (size_t)F * h4 * w4 * oc[3], &l4));
-        {
-            int mx = oc[0];
-            for (int j = 1; j < 4; ++j) mx = oc[j] > mx ? oc[j] : mx;
-            EDV_TRY(wsbuf("pj", (size_t)MP * mx, &pj));
-        }
+        float *pjs[4];  // one projection buffer per level: the four level chains below may run on two streams
+        for (int j = 0; j < 4; ++j) EDV_TRY(wsbuf("pj" + std::to_string(j), (size_t)MP * oc[j], &pjs[j]));
+        float *r1, *r2, *r3, *r4;
+        EDV_TRY(wsbuf("r1", (size_t)F * h1 * w1 * Fe, &r1));
+        EDV_TRY(wsbuf("r2", (size_t)F * h2 * w2 * Fe, &r2));
+        EDV_TRY(wsbuf("r3", (size_t)F * h3 * w3 * Fe, &r3));
+        EDV_TRY(wsbuf("r4", (size_t)F * h4 * w4 * Fe, &r4));
         float *readout = nullptr, *fbias = nullptr;
         if (cfg.use_clstoken) {
             EDV_TRY(wsbuf("readout", (size_t)MP * D, &readout));
             EDV_TRY(wsbuf("readout.fb", (size_t)F * D, &fbias));
         }
-        for (int j = 0; j < 4; ++j) {
+        // level j: tap -> 1x1 project -> resize -> (motion module on levels 3, 4) -> 3x3 layerN_rn  (dpt_pyramid.py:52-78)
+        auto level = [&](int j) -> int {
+            pj = pjs[j];
             const std::string pp = "head.projects." + std::to_string(j);
             const float *w, *b;
             const float *src = tap[j];
@@ -738,7 +744,7 @@ struct Run {
             }
             EDV_TRY(param(pp + ".weight", &w, 4));
             EDV_TRY(param(pp + ".bias", &b));
-            float *dst = (j == 2) ? l3 : pj;
+            float *dst = (j == 2) ? l3 : pj;  // level 3 is not resized: project straight into l3
             EDV_TRY(linear(src, MP, D, w, oc[j], b, dst));
             if (j < 2) {
                 const int s = j == 0 ? 4 : 2;
@@ -757,28 +763,47 @@ struct Run {
                 EDV_TRY(param("head.resize_layers.3.bias", &bc));
                 EDV_TRY(conv3(pj, ph, pw, oc[3], wc, bc, oc[3], 2, l4, false));
             }
+            if (j == 2) EDV_TRY(motion_module(0, l3, h3 * w3, oc[2]));
+            if (j == 3) EDV_TRY(motion_module(1, l4, h4 * w4, oc[3]));
+            float *const ls[4] = {l1, l2, l3, l4}, *const rs[4] = {r1, r2, r3, r4};
+            const int hs[4] = {h1, h2, h3, h4}, wsz[4] = {w1, w2, w3, w4};
+            const float *wr;
+            EDV_TRY(packedw("head.scratch.layer" + std::to_string(j + 1) + "_rn.weight", &wr));
+            EDV_TRY(conv3(ls[j], hs[j], wsz[j], oc[j], wr, nullptr, Fe, 1, rs[j], false));
+            return 0;
+        };
+        // The four level chains are independent until the fusion blocks and made of small kernels (7-80 us, a few hundred
+        // workgroups each): level 4 -- the longest, with its stride-2 conv and the C = out_channels[3] motion module -- goes
+        // to an internal stream, levels 3, 1, 2 stay on the caller's.  Not while training (saved activations are ordered by
+        // the backward), with use_clstoken (shared readout scratch) or during a stage capture.
+        static const int head_streams = [] {
+            const char *e = getenv("EDV_HEAD_STREAMS");  // 1 = all four levels on the caller's stream, 2 (default), 3
+            const int v = e ? atoi(e) : 2;
+            return v < 1 ? 1 : (v > 3 ? 3 : v);
+        }();
+        if (head_streams > 1 && !c->train && !cfg.use_clstoken && !c->capture) {
+            EDV_TRY(ensure_streams());
+            hipStream_t user = st;
+            EDV_HIP(hipEventRecord(c->ev_fork, user));
+            const int nsub = head_streams - 1;  // level 4 on sub[0]; with three streams level 3 on sub[1]
+            for (int h = 0; h < nsub; ++h) {
+                EDV_HIP(hipStreamWaitEvent(c->sub[h], c->ev_fork, 0));
+                st = c->sub[h];
+                const int rc = level(h == 0 ? 3 : 2);
+                st = user;
+                if (rc) return rc;
+                EDV_HIP(hipEventRecord(c->ev_join[h], c->sub[h]));
+            }
+            if (nsub == 1) EDV_TRY(level(2));
+            EDV_TRY(level(0));
+            EDV_TRY(level(1));
+            for (int h = 0; h < nsub; ++h) EDV_HIP(hipStreamWaitEvent(user, c->ev_join[h], 0));
+        } else {
+            for (int j = 0; j < 4; ++j) EDV_TRY(level(j));
         }
-        EDV_TRY(motion_module(0, l3, h3 * w3, oc[2]));
-        EDV_TRY(motion_module(1, l4, h4 * w4, oc[3]));
         c->stages["mm0"] = {l3, (size_t)F * h3 * w3 * oc[2]};
         c->stages["mm1"] = {l4, (size_t)F * h4 * w4 * oc[3]};
 
-        float *r1, *r2, *r3, *r4;
-        EDV_TRY(wsbuf("r1", (size_t)F * h1 * w1 * Fe, &r1));
-        EDV_TRY(wsbuf("r2", (size_t)F * h2 * w2 * Fe, &r2));
-        EDV_TRY(wsbuf("r3", (size_t)F * h3 * w3 * Fe, &r3));
-        EDV_TRY(wsbuf("r4", (size_t)F * h4 * w4 * Fe, &r4));
-        {
-            const float *w;
-            EDV_TRY(packedw("head.scratch.layer1_rn.weight", &w));
-            EDV_TRY(conv3(l1, h1, w1, oc[0], w, nullptr, Fe, 1, r1, false));
-            EDV_TRY(packedw("head.scratch.layer2_rn.weight", &w));
-            EDV_TRY(conv3(l2, h2, w2, oc[1], w, nullptr, Fe, 1, r2, false));
-            EDV_TRY(packedw("head.scratch.layer3_rn.weight", &w));
-            EDV_TRY(conv3(l3, h3, w3, oc[2], w, nullptr, Fe, 1, r3, false));
-            EDV_TRY(packedw("head.scratch.layer4_rn.weight", &w));
-            EDV_TRY(conv3(l4, h4, w4, oc[3], w, nullptr, Fe, 1, r4, false));
-        }
         const int h0 = 8 * ph, w0 = 8 * pw;
         float *p4, *p3, *p2, *p1;
         EDV_TRY(wsbuf("p4", (size_t)F * h3 * w3 * Fe, &p4));

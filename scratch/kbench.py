@@ -104,7 +104,7 @@ elif __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "sweep":
         gemm(M, 384, 384, res=True, label=f"proj T{T}")
         gemm(M, 384, 1536, res=True, label=f"fc2 T{T}")
         attn(T, 1370, 6)
-elif __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("attnbwd", "tattn")):
+elif __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("attnbwd", "tattn", "head")):
     M = 8 * 1370
     gemm(M, 1152, 384, label="qkv")
     gemm(M, 1536, 384, act=1, label="fc1+gelu")
@@ -148,3 +148,18 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "tattn":
     import os
     print("EDV_TATTN_PER_QUERY", os.environ.get("EDV_TATTN_PER_QUERY"))
     tattn(1, 8, 1369, 192); tattn(1, 8, 361, 384); tattn(1, 8, 1369, 64); tattn(1, 8, 5476, 64); tattn(1, 4, 5476, 64)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "head":
+    for (M, Cc, tag) in ((10952, 192, "mm0"), (2888, 384, "mm1"), (10952, 64, "mm2"), (43808, 64, "mm3")):
+        gemm(M, Cc, Cc, label=f"{tag} proj_in")
+        gemm(M, 3 * Cc, Cc, label=f"{tag} qkv")
+        gemm(M, Cc, Cc, res=True, label=f"{tag} to_out")
+        gemm(M, 8 * Cc, Cc, label=f"{tag} ff1")
+        gemm(M, Cc, 4 * Cc, res=True, label=f"{tag} ff2")
+    for (N, tag) in ((48, "proj0"), (96, "proj1"), (192, "proj2"), (384, "proj3")):
+        gemm(10952, N, 384, label=tag)
+    gemm(10952, 768, 48, label="convT4")
+    gemm(10952, 384, 96, label="convT2")
+    for (M, tag) in ((2888, "oc4"), (10952, "oc3"), (43808, "oc2"), (175232, "oc1")):
+        gemm(M, 64, 64, label=tag)

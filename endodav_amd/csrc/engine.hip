@@ -56,6 +56,7 @@ struct edv_ctx {
     int enc_streams = 1;                      // 2: run the two halves of the frame batch through the encoder concurrently
     hipStream_t sub[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_x[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // cross-stream edges of the head (r3, r1r2, u3, u2, u1)
     std::unordered_map<std::string, Param> params;
     std::unordered_map<std::string, Buf> packed;  // derived weights, owned
     std::unordered_map<std::string, Buf> ws;      // activations, owned
@@ -348,7 +349,8 @@ struct Run {
     }
 
     // ---- motion module, in place on x [F, P, C] channels-last (motion_module.py:102-126,164-177) ----
-    int motion_module(int m, float *x, int P, int C) {
+    // extra (optional, shaped like x): added to the output as well -- the skip branch of the following fusion block
+    int motion_module(int m, float *x, int P, int C, const float *extra = nullptr) {
         const std::string p = "head.motion_modules." + std::to_string(m) + ".temporal_transformer";
         const std::string tb = p + ".transformer_blocks.0";
         const long long M = (long long)F * P;
@@ -412,7 +414,14 @@ struct Run {
         EDV_TRY(linear(ff2, M, 4 * C, w, C, b, hs[3], ACT_NONE, nullptr, hs[2]));
         EDV_TRY(param(p + ".proj_out.weight", &w));
         EDV_TRY(param(p + ".proj_out.bias", &b));
-        EDV_TRY(linear(hs[3], M, C, w, C, b, x, ACT_NONE, nullptr, x));
+        {
+            GemmDesc g;
+            g.A = hs[3]; g.lda = C; g.W = w; g.ldw = C; g.C = x; g.ldc = C; g.M = M; g.N = C; g.K = C;
+            g.bias = b; g.R1 = x; g.ldr1 = C; g.R2 = extra; g.ldr2 = C;
+            c->launches++;
+            Bracket b_(c, KC_LINEAR, st);
+            EDV_TRY(gemm_ws(g));
+        }
         return 0;
     }
 
@@ -458,6 +467,42 @@ struct Run {
         EDV_TRY(param(p + ".out_conv.bias", &bo));
         EDV_TRY(linear(t2, (long long)F * h * w, Fe, wo, Fe, bo, t1));
         EDV_TRY(bilinear(t1, out, F, h, w, Fe, oh, ow, ACT_NONE, st));
+        c->launches++;
+        return 0;
+    }
+
+    // The skip branch of fusion block j without its x:  u = skip + conv2(relu(conv1(relu(skip))))  (resConfUnit1, blocks.py:146).
+    // It depends on layerN_rn only, so it can run beside the fusion chain on another stream; whoever produces x adds u.
+    int fusion_skip_branch(int j, const float *skip, int h, int w, float *u) {
+        const std::string p = "head.scratch.refinenet" + std::to_string(j);
+        float *t;
+        EDV_TRY(wsbuf("fus.t" + std::to_string(j), (size_t)F * h * w * Fe, &t));
+        const float *w1, *b1, *w2, *b2;
+        EDV_TRY(packedw(p + ".resConfUnit1.conv1.weight", &w1));
+        EDV_TRY(param(p + ".resConfUnit1.conv1.bias", &b1));
+        EDV_TRY(packedw(p + ".resConfUnit1.conv2.weight", &w2));
+        EDV_TRY(param(p + ".resConfUnit1.conv2.bias", &b2));
+        EDV_TRY(conv3(skip, h, w, Fe, w1, b1, Fe, 1, t, true));
+        return conv3(t, h, w, Fe, w2, b2, Fe, 1, u, true, ACT_NONE, skip, nullptr);
+    }
+    // The rest of fusion block j from s = x + u:  out = up(out_conv(s + conv2(relu(conv1(relu(s)))))) (+ add)
+    int fusion_tail(int j, const float *sx, int h, int w, int oh, int ow, float *out, const float *add) {
+        const std::string p = "head.scratch.refinenet" + std::to_string(j);
+        const size_t n = (size_t)F * h * w * Fe;
+        float *t1, *t2;
+        EDV_TRY(wsbuf("fu.t1", n, &t1));
+        EDV_TRY(wsbuf("fu.t2", n, &t2));
+        const float *w1, *b1, *w2, *b2, *wo, *bo;
+        EDV_TRY(packedw(p + ".resConfUnit2.conv1.weight", &w1));
+        EDV_TRY(param(p + ".resConfUnit2.conv1.bias", &b1));
+        EDV_TRY(packedw(p + ".resConfUnit2.conv2.weight", &w2));
+        EDV_TRY(param(p + ".resConfUnit2.conv2.bias", &b2));
+        EDV_TRY(conv3(sx, h, w, Fe, w1, b1, Fe, 1, t1, true));
+        EDV_TRY(conv3(t1, h, w, Fe, w2, b2, Fe, 1, t2, true, ACT_NONE, sx, nullptr));
+        EDV_TRY(param(p + ".out_conv.weight", &wo));
+        EDV_TRY(param(p + ".out_conv.bias", &bo));
+        EDV_TRY(linear(t2, (long long)F * h * w, Fe, wo, Fe, bo, t1));
+        EDV_TRY(bilinear(t1, out, F, h, w, Fe, oh, ow, ACT_NONE, st, add));
         c->launches++;
         return 0;
     }
@@ -516,6 +561,7 @@ struct Run {
             EDV_HIP(hipEventCreateWithFlags(&c->ev_join[h], hipEventDisableTiming));
         }
         EDV_HIP(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        for (int k = 0; k < 6; ++k) EDV_HIP(hipEventCreateWithFlags(&c->ev_x[k], hipEventDisableTiming));
         return 0;
     }
     // encoder on frames [f0, f0 + nf) enqueued on stream s (vision_transformer.py:279-289 + :317-321)
@@ -777,45 +823,85 @@ struct Run {
         // to an internal stream, levels 3, 1, 2 stay on the caller's.  Not while training (saved activations are ordered by
         // the backward), with use_clstoken (shared readout scratch) or during a stage capture.
         static const int head_streams = [] {
-            const char *e = getenv("EDV_HEAD_STREAMS");  // 1 = all four levels on the caller's stream, 2 (default), 3
+            const char *e = getenv("EDV_HEAD_STREAMS");  // 1 = everything on the caller's stream, 2 (default) = one internal stream beside it
             const int v = e ? atoi(e) : 2;
-            return v < 1 ? 1 : (v > 3 ? 3 : v);
+            return v < 1 ? 1 : (v > 2 ? 2 : v);
         }();
-        if (head_streams > 1 && !c->train && !cfg.use_clstoken && !c->capture) {
-            EDV_TRY(ensure_streams());
-            hipStream_t user = st;
-            EDV_HIP(hipEventRecord(c->ev_fork, user));
-            const int nsub = head_streams - 1;  // level 4 on sub[0]; with three streams level 3 on sub[1]
-            for (int h = 0; h < nsub; ++h) {
-                EDV_HIP(hipStreamWaitEvent(c->sub[h], c->ev_fork, 0));
-                st = c->sub[h];
-                const int rc = level(h == 0 ? 3 : 2);
-                st = user;
-                if (rc) return rc;
-                EDV_HIP(hipEventRecord(c->ev_join[h], c->sub[h]));
-            }
-            if (nsub == 1) EDV_TRY(level(2));
-            EDV_TRY(level(0));
-            EDV_TRY(level(1));
-            for (int h = 0; h < nsub; ++h) EDV_HIP(hipStreamWaitEvent(user, c->ev_join[h], 0));
-        } else {
-            for (int j = 0; j < 4; ++j) EDV_TRY(level(j));
-        }
-        c->stages["mm0"] = {l3, (size_t)F * h3 * w3 * oc[2]};
-        c->stages["mm1"] = {l4, (size_t)F * h4 * w4 * oc[3]};
-
         const int h0 = 8 * ph, w0 = 8 * pw;
         float *p4, *p3, *p2, *p1;
         EDV_TRY(wsbuf("p4", (size_t)F * h3 * w3 * Fe, &p4));
         EDV_TRY(wsbuf("p3", (size_t)F * h2 * w2 * Fe, &p3));
         EDV_TRY(wsbuf("p2", (size_t)F * h1 * w1 * Fe, &p2));
         EDV_TRY(wsbuf("p1", (size_t)F * h0 * w0 * Fe, &p1));
-        EDV_TRY(fusion(4, r4, nullptr, h4, w4, h3, w3, p4));
-        EDV_TRY(motion_module(2, p4, h3 * w3, Fe));
-        EDV_TRY(fusion(3, p4, r3, h3, w3, h2, w2, p3));
-        EDV_TRY(motion_module(3, p3, h2 * w2, Fe));
-        EDV_TRY(fusion(2, p3, r2, h2, w2, h1, w1, p2));
-        EDV_TRY(fusion(1, p2, r1, h1, w1, h0, w0, p1));
+        if (head_streams > 1 && !c->train && !cfg.use_clstoken && !c->capture) {
+            // internal stream: level 4, then the skip branches u3, u2, u1 of the fusion blocks (they need layerN_rn only);
+            // caller's stream: levels 3, 1, 2, then the fusion chain, where whoever produces a block's x adds its u:
+            // motion modules 2 and 3 in their proj_out epilogue, fusion block 2 in its upsample.
+            EDV_TRY(ensure_streams());
+            float *u1, *u2, *u3;
+            EDV_TRY(wsbuf("fu.u1", (size_t)F * h1 * w1 * Fe, &u1));
+            EDV_TRY(wsbuf("fu.u2", (size_t)F * h2 * w2 * Fe, &u2));
+            EDV_TRY(wsbuf("fu.u3", (size_t)F * h3 * w3 * Fe, &u3));
+            hipStream_t user = st, side = c->sub[0];
+            EDV_HIP(hipEventRecord(c->ev_fork, user));
+            EDV_HIP(hipStreamWaitEvent(side, c->ev_fork, 0));
+            st = side;
+            int rc = level(3);
+            st = user;
+            if (rc) return rc;
+            EDV_HIP(hipEventRecord(c->ev_join[0], side));     // r4 ready
+            EDV_TRY(level(2));
+            if (cfg.conv_head) {  // the four HeadDepth heads read path_4..path_1 themselves: no folding of u into them
+                EDV_TRY(level(0));
+                EDV_TRY(level(1));
+                EDV_HIP(hipStreamWaitEvent(user, c->ev_join[0], 0));
+                EDV_TRY(fusion(4, r4, nullptr, h4, w4, h3, w3, p4));
+                EDV_TRY(motion_module(2, p4, h3 * w3, Fe));
+                EDV_TRY(fusion(3, p4, r3, h3, w3, h2, w2, p3));
+                EDV_TRY(motion_module(3, p3, h2 * w2, Fe));
+                EDV_TRY(fusion(2, p3, r2, h2, w2, h1, w1, p2));
+                EDV_TRY(fusion(1, p2, r1, h1, w1, h0, w0, p1));
+            } else {
+                EDV_HIP(hipEventRecord(c->ev_x[0], user));        // r3 ready
+                EDV_HIP(hipStreamWaitEvent(side, c->ev_x[0], 0));
+                st = side;
+                rc = fusion_skip_branch(3, r3, h3, w3, u3);
+                st = user;
+                if (rc) return rc;
+                EDV_HIP(hipEventRecord(c->ev_x[2], side));        // u3 ready
+                EDV_TRY(level(0));
+                EDV_TRY(level(1));
+                EDV_HIP(hipEventRecord(c->ev_x[1], user));        // r1, r2 ready
+                EDV_HIP(hipStreamWaitEvent(side, c->ev_x[1], 0));
+                st = side;
+                rc = fusion_skip_branch(2, r2, h2, w2, u2);
+                if (!rc) EDV_HIP(hipEventRecord(c->ev_x[3], side));  // u2 ready
+                if (!rc) rc = fusion_skip_branch(1, r1, h1, w1, u1);
+                st = user;
+                if (rc) return rc;
+                EDV_HIP(hipEventRecord(c->ev_x[4], side));        // u1 ready
+                EDV_HIP(hipStreamWaitEvent(user, c->ev_join[0], 0));
+                EDV_TRY(fusion(4, r4, nullptr, h4, w4, h3, w3, p4));
+                EDV_HIP(hipStreamWaitEvent(user, c->ev_x[2], 0));
+                EDV_TRY(motion_module(2, p4, h3 * w3, Fe, u3));   // p4 <- motion(p4) + u3 = the s of fusion block 3
+                EDV_TRY(fusion_tail(3, p4, h3, w3, h2, w2, p3, nullptr));
+                EDV_HIP(hipStreamWaitEvent(user, c->ev_x[3], 0));
+                EDV_TRY(motion_module(3, p3, h2 * w2, Fe, u2));   // p3 <- motion(p3) + u2
+                EDV_HIP(hipStreamWaitEvent(user, c->ev_x[4], 0));
+                EDV_TRY(fusion_tail(2, p3, h2, w2, h1, w1, p2, u1));  // p2 <- up(...) + u1
+                EDV_TRY(fusion_tail(1, p2, h1, w1, h0, w0, p1, nullptr));
+            }
+        } else {
+            for (int j = 0; j < 4; ++j) EDV_TRY(level(j));
+            EDV_TRY(fusion(4, r4, nullptr, h4, w4, h3, w3, p4));
+            EDV_TRY(motion_module(2, p4, h3 * w3, Fe));
+            EDV_TRY(fusion(3, p4, r3, h3, w3, h2, w2, p3));
+            EDV_TRY(motion_module(3, p3, h2 * w2, Fe));
+            EDV_TRY(fusion(2, p3, r2, h2, w2, h1, w1, p2));
+            EDV_TRY(fusion(1, p2, r1, h1, w1, h0, w0, p1));
+        }
+        c->stages["mm0"] = {l3, (size_t)F * h3 * w3 * oc[2]};
+        c->stages["mm1"] = {l4, (size_t)F * h4 * w4 * oc[3]};
         c->stages["path4"] = {p4, (size_t)F * h3 * w3 * Fe};
         c->stages["path3"] = {p3, (size_t)F * h2 * w2 * Fe};
         c->stages["path2"] = {p2, (size_t)F * h1 * w1 * Fe};
@@ -1325,6 +1411,8 @@ int edv_destroy(edv_ctx *ctx) {
         if (ctx->ev_join[h]) (void)hipEventDestroy(ctx->ev_join[h]);
     }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    for (int k = 0; k < 6; ++k)
+        if (ctx->ev_x[k]) (void)hipEventDestroy(ctx->ev_x[k]);
     for (auto &p : ctx->prof)
         for (auto &e : p.ev) {
             (void)hipEventDestroy(e.first);

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float *__restrict__
 
 // thread per (output pixel, float4 of channels)
 __global__ __launch_bounds__(256) void bilinear_c4_kernel(const float *__restrict__ x, float *__restrict__ y, int F, int H, int W, int C4, int OH,
-                                                           int OW, float rh, float rw) {
+                                                           int OW, float rh, float rw, const float *__restrict__ add) {
     const long long total = (long long)F * OH * OW * C4;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % C4);
@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256) void bilinear_c4_kernel(const float *__restric
         const f32x4 *pl = reinterpret_cast<const f32x4 *>(x) + f * H * W * C4 + c;
         const f32x4 v00 = pl[((long long)y0 * W + x0) * C4], v01 = pl[((long long)y0 * W + x1) * C4];
         const f32x4 v10 = pl[((long long)y1 * W + x0) * C4], v11 = pl[((long long)y1 * W + x1) * C4];
-        reinterpret_cast<f32x4 *>(y)[i] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+        f32x4 o = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+        if (add) o += reinterpret_cast<const f32x4 *>(add)[i];  // the skip branch of the next fusion block, shaped like y
+        reinterpret_cast<f32x4 *>(y)[i] = o;
     }
 }
 
@@ -207,17 +209,18 @@ int patchify(const float *x, float *cols, int F, int H, int W, int ih, int iw, h
     return 0;
 }
 
-int bilinear(const float *x, float *y, int F, int H, int W, int C, int OH, int OW, int act, hipStream_t st) {
+int bilinear(const float *x, float *y, int F, int H, int W, int C, int OH, int OW, int act, hipStream_t st, const float *add) {
     EDV_CHECK(x && y, "null operand");
     EDV_CHECK(F > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "empty problem");
     EDV_CHECK(act == ACT_NONE, "bilinear: fused activation not implemented");
     EDV_CHECK(C == 1 || C % 4 == 0, "C must be 1 or a multiple of 4");
+    EDV_CHECK(!add || C % 4 == 0, "bilinear: the addend needs C % 4 == 0");
     const float rh = lin_ratio(H, OH), rw = lin_ratio(W, OW);
     if (C == 1) {
         hipLaunchKernelGGL(bilinear_c1_kernel, dim3(grid_for((long long)F * OH * OW)), dim3(256), 0, st, x, y, F, H, W, OH, OW, rh, rw);
     } else {
         hipLaunchKernelGGL(bilinear_c4_kernel, dim3(grid_for((long long)F * OH * OW * (C / 4), 16384)), dim3(256), 0, st, x, y, F, H, W, C / 4, OH, OW,
-                           rh, rw);
+                           rh, rw, add);
     }
     EDV_LAUNCH_OK();
     return 0;

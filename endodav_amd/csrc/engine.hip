@@ -833,7 +833,9 @@ struct Run {
         EDV_TRY(wsbuf("p3", (size_t)F * h2 * w2 * Fe, &p3));
         EDV_TRY(wsbuf("p2", (size_t)F * h1 * w1 * Fe, &p2));
         EDV_TRY(wsbuf("p1", (size_t)F * h0 * w0 * Fe, &p1));
-        if (head_streams > 1 && !c->train && !cfg.use_clstoken && !c->capture) {
+        // Measured (profiles/r01_gemm_tile_sweep.txt): +3 % at T = 8 and 16, -0.8 % at T = 32, where the head's kernels fill the
+        // GPU on their own -- so only up to 16 frames per clip.
+        if (head_streams > 1 && T <= 16 && !c->train && !cfg.use_clstoken && !c->capture) {
             // internal stream: level 4, then the skip branches u3, u2, u1 of the fusion blocks (they need layerN_rn only);
             // caller's stream: levels 3, 1, 2, then the fusion chain, where whoever produces a block's x adds its u:
             // motion modules 2 and 3 in their proj_out epilogue, fusion block 2 in its upsample.

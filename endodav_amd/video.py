@@ -17,7 +17,7 @@ network's size the resize is the identity and the whole path is pinned by ``test
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Tuple
+from typing import List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -118,15 +118,41 @@ def infer_video_depth(model, frames, input_size=518, device="cuda"):
             vid = small
         index = torch.arange(total, device=dev).clamp_(max=n - 1)  # padding = copies of the last frame
 
+        # The reference copies every window to the host synchronously (endodav.py:205-206).  Here the D2H of window k runs on
+        # a copy stream into one of two pinned buffers while window k+1 is computed; the host only waits for a buffer when
+        # it is about to be reused (host-side copies must not gate the GPU).
         windows: List[np.ndarray] = []
+        copy_stream = torch.cuda.Stream(device=dev)
+        ring = [torch.empty((INFER_LEN, fh, fw), dtype=torch.float32).pin_memory() for _ in range(min(2, len(starts)))]
+        dev_full = [torch.empty((INFER_LEN, fh, fw), device=dev, dtype=torch.float32) for _ in ring]
+        done: List[Optional[torch.cuda.Event]] = [None] * len(ring)
+
+        def drain(slot: int) -> None:
+            if done[slot] is not None:
+                done[slot].synchronize()
+                windows.append(ring[slot].numpy().copy())
+                done[slot] = None
+
         pre = None
-        for s0 in starts:
+        for k, s0 in enumerate(starts):
+            slot = k % len(ring)
+            drain(slot)  # also frees dev_full[slot]: its copy has completed
             cur = vid[index[s0:s0 + INFER_LEN]].unsqueeze(0).contiguous()  # [1,32,3,th,tw]
             if pre is not None:
                 cur[:, :OVERLAP] = pre[:, KEYFRAMES]
             disp = model(cur)[("disp", 0)]  # [32,1,ih,iw]
-            full = torch.empty((INFER_LEN, fh, fw), device=dev, dtype=torch.float32)
+            full = dev_full[slot]
             _lib.check(lib.edv_bilinear(disp.data_ptr(), full.data_ptr(), INFER_LEN, disp.shape[-2], disp.shape[-1], 1, fh, fw, st), "edv_bilinear")
-            windows.append(full.cpu().numpy())
+            ready = torch.cuda.Event()
+            ready.record(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(copy_stream):
+                copy_stream.wait_event(ready)
+                ring[slot].copy_(full, non_blocking=True)
+                done[slot] = torch.cuda.Event()
+                done[slot].record(copy_stream)
             pre = cur
+        # windows must come out in order: drain the remaining slots oldest first
+        for k in range(len(starts) - len(ring), len(starts)):
+            if k >= 0:
+                drain(k % len(ring))
     return stitch_windows(windows, n)

@@ -79,7 +79,8 @@ SIGNATURES = {
     "edv_backward": (C.c_int, [C.c_void_p, _fp, C.POINTER(C.c_void_p), C.c_void_p]),
     "edv_grad": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(_i64)]),
     "edv_grad_copy": (C.c_int, [C.c_void_p, C.c_char_p, _fp, _i64, C.c_void_p]),
-    "edv_attn_spatial_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, C.c_void_p]),
+    "edv_attn_spatial_bwd_workspace": (C.c_size_t, [_i32, _i32, _i32]),
+    "edv_attn_spatial_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _fp, C.c_size_t, C.c_void_p]),
     "edv_layernorm_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _i64, _i32, C.c_float, _i32, C.c_void_p]),
     "edv_ew_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _i64, _i32, C.c_void_p]),
     "edv_geglu_bwd": (C.c_int, [_fp, _fp, _fp, _i64, _i32, C.c_void_p]),

@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float *__restrict
 // NW waves (32 resident rows each) per workgroup share the streamed tiles
 template <int MODE, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_spatial_bwd_kernel(const float *__restrict__ qkv, const float *__restrict__ dO, const float *__restrict__ lse,
-                                                               const float *__restrict__ delta, float *__restrict__ dqkv, int N, int heads) {
+                                                               const float *__restrict__ delta, float *__restrict__ dqkv, float *__restrict__ ws, int N,
+                                                               int heads, int whole_rounds, long long units, int chunk) {
     __shared__ __attribute__((aligned(16))) float sT1[TR * TS];
     __shared__ __attribute__((aligned(16))) float sT2[TR * TS];
     __shared__ __attribute__((aligned(16))) float sL[TR];  // MODE_DKV: lse / delta of the streamed queries
@@ -60,10 +61,45 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_bwd_kernel(const float *
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
     constexpr int RB = NW * 32, NT = NW * 64;
+    constexpr int OC = MODE == MODE_DQ ? HD : 2 * HD;  // output columns per resident row: dQ | dK, dV
     const int nb = (N + RB - 1) / RB;
-    const int blk = blockIdx.x % nb, fh = blockIdx.x / nb;
-    const int head = fh % heads, frame = fh / heads;
     const int D = heads * HD, D3 = 3 * D;
+    const int ntiles = (N + TR - 1) / TR;
+    // Persistent workgroups, whole tasks first, the last partial round split along the STREAMED axis -- the scheduling of
+    // attn_spatial.hip.  The gradients are plain sums over the streamed rows, so a piece just leaves its raw accumulators in
+    // workspace slot (id * 2 + run) and attn_bwd_combine_kernel adds the pieces of a task.
+    const int G = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = G >> 3, r = G & 7, x = bid & 7, loc = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+    }
+    const int task_l0 = whole_rounds * G;
+    long long u = (long long)bid * chunk;
+    const long long u_end = u + chunk < units ? u + chunk : units;
+    int round = 0, seg = 0;
+    for (;;) {
+    int task, kt0, kt1;
+    float *part = nullptr;
+    if (round < whole_rounds) {
+        task = round * G + bid;
+        kt0 = 0;
+        kt1 = ntiles;
+        ++round;
+    } else if (u < u_end) {
+        const int t = (int)(u / ntiles);
+        kt0 = (int)(u - (long long)t * ntiles);
+        const long long left = u_end - u;
+        kt1 = kt0 + left < ntiles ? kt0 + (int)left : ntiles;
+        task = task_l0 + t;
+        u += kt1 - kt0;
+        if (!(kt0 == 0 && kt1 == ntiles)) part = ws + ((long long)bid * 2 + seg) * (RB * OC);
+        ++seg;
+    } else {
+        break;
+    }
+    const int blk = task % nb, fh = task / nb;
+    const int head = fh % heads, frame = fh / heads;
     const float *base = qkv + (long long)frame * N * D3 + head * HD;    // q columns; k at +D, v at +2D
     const float *dobase = dO + (long long)frame * N * D + head * HD;
     const float *lrow = lse + ((long long)frame * heads + head) * N;
@@ -123,9 +159,8 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_bwd_kernel(const float *
         }
     };
 
-    const int ntiles = (N + TR - 1) / TR;
-    load_tile(0);
-    for (int t = 0; t < ntiles; ++t) {
+    load_tile(kt0 * TR);
+    for (int t = kt0; t < kt1; ++t) {
         const int t0 = t * TR;
         __syncthreads();
 #pragma unroll
@@ -140,7 +175,7 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_bwd_kernel(const float *
             sD[tid] = pd;
         }
         __syncthreads();
-        if (t + 1 < ntiles) load_tile(t0 + TR);
+        if (t + 1 < kt1) load_tile(t0 + TR);
 
         // ---- X1^T = T1 R1^T (scores, base-2 logits), X2^T = T2 R2^T (dP)
         f32x16 x1, x2;
@@ -194,7 +229,18 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_bwd_kernel(const float *
         }
     }
 
-    if (ri < N) {
+    if (part) {  // raw accumulators of a piece: row-major [RB][OC], scaled by the combine kernel
+        float *prow = part + (wave * 32 + l31) * OC;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            *reinterpret_cast<f32x4 *>(prow + 8 * g + 4 * lh) = f32x4{o0[4 * g], o0[4 * g + 1], o0[4 * g + 2], o0[4 * g + 3]};
+            *reinterpret_cast<f32x4 *>(prow + 32 + 8 * g + 4 * lh) = f32x4{o1[4 * g], o1[4 * g + 1], o1[4 * g + 2], o1[4 * g + 3]};
+            if (MODE == MODE_DKV) {
+                *reinterpret_cast<f32x4 *>(prow + HD + 8 * g + 4 * lh) = f32x4{o2[4 * g], o2[4 * g + 1], o2[4 * g + 2], o2[4 * g + 3]};
+                *reinterpret_cast<f32x4 *>(prow + HD + 32 + 8 * g + 4 * lh) = f32x4{o3[4 * g], o3[4 * g + 1], o3[4 * g + 2], o3[4 * g + 3]};
+            }
+        }
+    } else if (ri < N) {
         float *orow = dqkv + ((long long)frame * N + ri) * D3 + head * HD + (MODE == MODE_DQ ? 0 : D);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {  // registers 4g..4g+3 are d = 8g + 4*lh + {0..3}
@@ -210,13 +256,101 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_bwd_kernel(const float *
             }
         }
     }
+    }  // work list
+}
+
+// Adds the pieces of every split task and writes dQ (x d^-1/2) or dK (x d^-1/2) | dV.  Thread = (row, float4 of columns).
+template <int MODE>
+__global__ __launch_bounds__(256) void attn_bwd_combine_kernel(const float *__restrict__ ws, float *__restrict__ dqkv, int N, int heads, int RB, int ntiles,
+                                                               int task_l0, int chunk) {
+    constexpr int OC = MODE == MODE_DQ ? HD : 2 * HD;
+    const int t = blockIdx.x;
+    const long long ub = (long long)t * ntiles, ue = ub + ntiles;
+    const int g0 = (int)(ub / chunk), g1 = (int)((ue - 1) / chunk);
+    if (g0 == g1 && (long long)g0 * chunk <= ub && (long long)(g0 + 1) * chunk >= ue) return;  // ran whole
+    const int idx = blockIdx.y * 256 + threadIdx.x;  // float4 slot within [RB][OC]
+    if (idx >= RB * OC / 4) return;
+    const int row = idx / (OC / 4), c4 = idx - row * (OC / 4);
+    const int nb = (N + RB - 1) / RB;
+    const int task = task_l0 + t;
+    const int blk = task % nb, fh = task / nb;
+    const int head = fh % heads, frame = fh / heads;
+    const int ri = blk * RB + row;
+    if (ri >= N) return;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int g = g0; g <= g1; ++g) {
+        const float *part = ws + ((long long)g * 2 + ((long long)g * chunk >= ub ? 0 : 1)) * (RB * OC);
+        acc += *reinterpret_cast<const f32x4 *>(part + row * OC + 4 * c4);
+    }
+    const int D = heads * HD, D3 = 3 * D;
+    const int col = 4 * c4;  // MODE_DQ: dq column; MODE_DKV: [0, 64) dk, [64, 128) dv
+    float *orow = dqkv + ((long long)frame * N + ri) * D3 + head * HD;
+    if (MODE == MODE_DQ)
+        *reinterpret_cast<f32x4 *>(orow + col) = acc * 0.125f;
+    else if (col < HD)
+        *reinterpret_cast<f32x4 *>(orow + D + col) = acc * 0.125f;
+    else
+        *reinterpret_cast<f32x4 *>(orow + 2 * D + (col - HD)) = acc;
+}
+
+struct BwdPlan {
+    int grid, whole_rounds, chunk, leftover, ntiles;
+    long long units;
+    size_t ws_floats;
+};
+
+template <int MODE, int NW>
+int bwd_slots() {
+    static const int slots = [] {
+        int dev = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, attn_spatial_bwd_kernel<MODE, NW>, NW * 64, 0) != hipSuccess) return 0;
+        return cus * per_cu;
+    }();
+    return slots;
+}
+
+BwdPlan make_bwd_plan(long long ntasks, int N, int slots, int rb, int oc, bool plain) {
+    BwdPlan p;
+    p.ntiles = (N + TR - 1) / TR;
+    if (plain || slots <= 0) {
+        p.grid = (int)ntasks; p.whole_rounds = 1; p.leftover = 0; p.units = 0; p.chunk = 1; p.ws_floats = 0;
+        return p;
+    }
+    p.whole_rounds = (int)(ntasks / slots);
+    p.leftover = (int)(ntasks - (long long)p.whole_rounds * slots);
+    p.units = (long long)p.leftover * p.ntiles;
+    p.chunk = p.units ? (int)((p.units + slots - 1) / slots) : 1;
+    p.grid = p.whole_rounds ? slots : (int)((p.units + p.chunk - 1) / p.chunk);
+    p.ws_floats = (size_t)((p.units + p.chunk - 1) / p.chunk) * 2 * (size_t)rb * oc;
+    return p;
 }
 
 }  // namespace
 
-// qkv [F*N, 3*heads*64], out/dout [F*N, heads*64], lse/delta [F, heads, N] (delta is scratch written here), dqkv like qkv
-int attn_spatial_bwd(const float *qkv, const float *out, const float *dout, const float *lse, float *delta, float *dqkv, int F, int N, int heads,
-                     hipStream_t st) {
+namespace {
+bool bwd_plain() {
+    static const bool plain = [] {
+        const char *e = getenv("EDV_ATTN_BWD_PLAIN");  // 1: one workgroup per task (A/B runs)
+        return e && atoi(e) != 0;
+    }();
+    return plain;
+}
+}  // namespace
+
+size_t attn_spatial_bwd_workspace(int F, int N, int heads) {
+    if (F <= 0 || N <= 0 || heads <= 0) return 0;
+    const long long ntasks = (long long)F * heads * ((N + 127) / 128);
+    const BwdPlan a = make_bwd_plan(ntasks, N, bwd_slots<MODE_DQ, 4>(), 128, HD, bwd_plain());
+    const BwdPlan b = make_bwd_plan(ntasks, N, bwd_slots<MODE_DKV, 4>(), 128, 2 * HD, bwd_plain());
+    return a.ws_floats > b.ws_floats ? a.ws_floats : b.ws_floats;
+}
+
+// qkv [F*N, 3*heads*64], out/dout [F*N, heads*64], lse/delta [F, heads, N] (delta is scratch written here), dqkv like qkv;
+// ws: attn_spatial_bwd_workspace(F, N, heads) floats (the two launches use it one after the other)
+int attn_spatial_bwd(const float *qkv, const float *out, const float *dout, const float *lse, float *delta, float *dqkv, int F, int N, int heads, float *ws,
+                     size_t ws_floats, hipStream_t st) {
     EDV_CHECK(qkv && out && dout && lse && delta && dqkv, "null operand");
     EDV_CHECK(F > 0 && N > 0 && heads > 0, "empty problem");
     EDV_CHECK(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)dout % 16 == 0) && ((uintptr_t)dqkv % 16 == 0), "16-byte alignment");
@@ -224,31 +358,30 @@ int attn_spatial_bwd(const float *qkv, const float *out, const float *dout, cons
     EDV_CHECK((pairs * 16 + 255) / 256 < (1ll << 31), "grid");
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((pairs * 16 + 255) / 256)), dim3(256), 0, st, dout, out, delta, F, N, heads);
     EDV_LAUNCH_OK();
-    // 4 waves per workgroup share each streamed tile.  2-wave workgroups (a finer grid against the nearly empty last round
-    // of 528 tasks on 512 slots at T=8) measured slower: 1046 vs 967 us at T=8, 3012 vs 2759 us at T=32 (117 TF/s over the
-    // seven products).  EDV_ATTN_BWD_WAVES=2 selects them for A/B runs.
-    static const int forced = [] {
-        const char *e = getenv("EDV_ATTN_BWD_WAVES");
-        return e ? atoi(e) : 0;
-    }();
-    const int nw = forced == 2 ? 2 : (forced == 3 ? 3 : 4);
-    const long long blocks = (long long)F * heads * ((N + nw * 32 - 1) / (nw * 32));
-    EDV_CHECK(blocks < (1ll << 31), "grid");
-    const dim3 grid((unsigned)blocks);
-    if (nw == 4) {
-        hipLaunchKernelGGL((attn_spatial_bwd_kernel<MODE_DQ, 4>), grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, N, heads);
-        EDV_LAUNCH_OK();
-        hipLaunchKernelGGL((attn_spatial_bwd_kernel<MODE_DKV, 4>), grid, dim3(256), 0, st, qkv, dout, lse, delta, dqkv, N, heads);
-    } else if (nw == 3) {
-        hipLaunchKernelGGL((attn_spatial_bwd_kernel<MODE_DQ, 3>), grid, dim3(192), 0, st, qkv, dout, lse, delta, dqkv, N, heads);
-        EDV_LAUNCH_OK();
-        hipLaunchKernelGGL((attn_spatial_bwd_kernel<MODE_DKV, 3>), grid, dim3(192), 0, st, qkv, dout, lse, delta, dqkv, N, heads);
-    } else {
-        hipLaunchKernelGGL((attn_spatial_bwd_kernel<MODE_DQ, 2>), grid, dim3(128), 0, st, qkv, dout, lse, delta, dqkv, N, heads);
-        EDV_LAUNCH_OK();
-        hipLaunchKernelGGL((attn_spatial_bwd_kernel<MODE_DKV, 2>), grid, dim3(128), 0, st, qkv, dout, lse, delta, dqkv, N, heads);
-    }
+    const long long ntasks = (long long)F * heads * ((N + 127) / 128);
+    EDV_CHECK(ntasks < (1ll << 31), "grid");
+    // 4 waves per workgroup share each streamed tile (2- and 3-wave workgroups measured slower: 1046 / 962 vs 947 us at T=8,
+    // 3012 / 3622 vs 2731 us at T=32).
+    const BwdPlan pq = make_bwd_plan(ntasks, N, bwd_slots<MODE_DQ, 4>(), 128, HD, bwd_plain());
+    const BwdPlan pk = make_bwd_plan(ntasks, N, bwd_slots<MODE_DKV, 4>(), 128, 2 * HD, bwd_plain());
+    const size_t need = pq.ws_floats > pk.ws_floats ? pq.ws_floats : pk.ws_floats;
+    EDV_CHECK(need == 0 || (ws && ws_floats >= need && (uintptr_t)ws % 16 == 0), "attention backward workspace too small (attn_spatial_bwd_workspace)");
+    hipLaunchKernelGGL((attn_spatial_bwd_kernel<MODE_DQ, 4>), dim3((unsigned)pq.grid), dim3(256), 0, st, qkv, dout, lse, delta, dqkv, ws, N, heads,
+                       pq.whole_rounds, pq.units, pq.chunk);
     EDV_LAUNCH_OK();
+    if (pq.leftover) {
+        hipLaunchKernelGGL(attn_bwd_combine_kernel<MODE_DQ>, dim3((unsigned)pq.leftover, (128 * HD / 4 + 255) / 256), dim3(256), 0, st, ws, dqkv, N, heads, 128,
+                           pq.ntiles, pq.whole_rounds * pq.grid, pq.chunk);
+        EDV_LAUNCH_OK();
+    }
+    hipLaunchKernelGGL((attn_spatial_bwd_kernel<MODE_DKV, 4>), dim3((unsigned)pk.grid), dim3(256), 0, st, qkv, dout, lse, delta, dqkv, ws, N, heads,
+                       pk.whole_rounds, pk.units, pk.chunk);
+    EDV_LAUNCH_OK();
+    if (pk.leftover) {
+        hipLaunchKernelGGL(attn_bwd_combine_kernel<MODE_DKV>, dim3((unsigned)pk.leftover, (128 * 2 * HD / 4 + 255) / 256), dim3(256), 0, st, ws, dqkv, N, heads,
+                           128, pk.ntiles, pk.whole_rounds * pk.grid, pk.chunk);
+        EDV_LAUNCH_OK();
+    }
     return 0;
 }
 

@@ -1271,6 +1271,9 @@ struct Run {
         EDV_TRY(wsbuf("g.e3", (size_t)MT * 3 * D, &t3));
         EDV_TRY(wsbuf("g.e4", (size_t)MT * 4 * D, &t4));
         EDV_TRY(wsbuf("g.delta", (size_t)F * heads * ntok, &delta));
+        float *abws = nullptr;
+        const size_t abws_n = attn_spatial_bwd_workspace(F, ntok, heads);
+        if (abws_n) EDV_TRY(wsbuf("g.attbws", abws_n, &abws));
         const int rank = cfg.lora_rank;
         const bool lora = cfg.lora_type != EDV_LORA_NONE;
         const size_t lws_n = lora_ws_n;
@@ -1307,7 +1310,7 @@ struct Run {
             if (i == 0) break;  // nothing trainable below block 0's MLP
             // x_mid = x_in + ls1 * proj(attn(qkv(norm1(x_in))))
             EDV_TRY(dgemm(dxt, MT, D, bp + ".attn.proj", D, t1));
-            EDV_TRY(attn_spatial_bwd(qkv, att, t1, lse, delta, t3, F, ntok, heads, st));
+            EDV_TRY(attn_spatial_bwd(qkv, att, t1, lse, delta, t3, F, ntok, heads, abws, abws_n, st));
             EDV_TRY(dgemm(t3, MT, 3 * D, bp + ".attn.qkv", D, t1));
             EDV_TRY(param(bp + ".norm1.weight", &w2));
             EDV_TRY(layernorm_bwd(x_in, identity_map(), w2, t1, identity_map(), dxt, identity_map(), MT, D, 1e-6f, true, st));

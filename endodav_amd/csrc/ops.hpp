@@ -73,8 +73,9 @@ const char *gemm_kernel_name(const GemmDesc &d);
 size_t attn_spatial_workspace(int F, int N, int heads);  // floats
 // lse (optional, [F, heads, N]): per-row log-sum-exp of the scores in base 2, for attn_spatial_bwd
 int attn_spatial(const float *qkv, float *out, int F, int N, int heads, float *ws, size_t ws_floats, hipStream_t st, float *lse = nullptr);
-int attn_spatial_bwd(const float *qkv, const float *out, const float *dout, const float *lse, float *delta, float *dqkv, int F, int N, int heads,
-                     hipStream_t st);
+size_t attn_spatial_bwd_workspace(int F, int N, int heads);  // floats
+int attn_spatial_bwd(const float *qkv, const float *out, const float *dout, const float *lse, float *delta, float *dqkv, int F, int N, int heads, float *ws,
+                     size_t ws_floats, hipStream_t st);
 int attn_temporal(const float *qkv, float *out, int B, int T, int P, int C, int heads, hipStream_t st);
 int geglu(const float *x, float *y, long long M, int inner, hipStream_t st);
 

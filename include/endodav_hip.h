@@ -153,8 +153,9 @@ int edv_attn_spatial(const float *qkv_dev, float *out_dev, int32_t F, int32_t N,
 /* lse_dev (optional, [F, heads, N]): per-row log-sum-exp of the scaled scores in base 2, the only extra state the
  * backward needs.  edv_attn_spatial_bwd: dqkv [F*N, 3*heads*64] (like qkv) from qkv, out, dout [F*N, heads*64] and lse;
  * delta_dev is [F, heads, N] floats of scratch. */
+size_t edv_attn_spatial_bwd_workspace(int32_t F, int32_t N, int32_t heads); /* bytes; the backward splits its last partial round too */
 int edv_attn_spatial_bwd(const float *qkv_dev, const float *out_dev, const float *dout_dev, const float *lse_dev, float *delta_dev,
-                         float *dqkv_dev, int32_t F, int32_t N, int32_t heads, void *stream);
+                         float *dqkv_dev, int32_t F, int32_t N, int32_t heads, float *workspace_dev, size_t workspace_bytes, void *stream);
 
 /* Temporal attention core, motion_module.py:230-297 + attention.py:182-211: qkv [B*T*P, 3C]
  * (q|k|v per row, 8 heads), softmax over the T frames of each pixel -> out [B*T*P, C]. */

@@ -128,7 +128,8 @@ def attn_bwd(F, N, heads):
     lse = torch.empty(F * heads * N, device=dev); delta = torch.empty(F * heads * N, device=dev); dq = torch.empty(F * N, 3 * D, device=dev)
     nb = lib.edv_attn_spatial_workspace(F, N, heads); ws = torch.empty(max(nb // 4, 4), device=dev)
     _lib.check(lib.edv_attn_spatial(qkv.data_ptr(), o.data_ptr(), F, N, heads, ws.data_ptr(), nb, lse.data_ptr(), st()))
-    t = timeit(lambda: _lib.check(lib.edv_attn_spatial_bwd(qkv.data_ptr(), o.data_ptr(), g.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), F, N, heads, st())))
+    nbb = lib.edv_attn_spatial_bwd_workspace(F, N, heads); wsb = torch.empty(max(nbb // 4, 4), device=dev)
+    t = timeit(lambda: _lib.check(lib.edv_attn_spatial_bwd(qkv.data_ptr(), o.data_ptr(), g.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq.data_ptr(), F, N, heads, wsb.data_ptr(), nbb, st())))
     print(f"attn_bwd F={F} N={N} heads={heads}: {t*1e6:8.1f} us  {14*N*N*64*heads*F/t/1e12:6.1f} TF (7 products)", flush=True)
 
 

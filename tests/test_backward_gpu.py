@@ -129,7 +129,9 @@ def test_vits_gradients_full_size(lib, cuda, H, W, T, resize_from):
     print(f"\n[vits {H}x{W} T={T}] {len(names)} tensors, worst scale-relative gradient error vs the fp64 graph {worst:.2e}")
 
 
-def test_training_forward_is_bit_identical_to_inference(lib, cuda):
+def test_training_forward_equals_inference(lib, cuda):
+    """Same kernels, same values; the inference path only orders the head differently (the fusion blocks' skip branches
+    run on a second stream and are added where x is produced), which moves the result by fp32 rounding."""
     model, kwargs, shape, kind, _ = build_model("micro_vda_dvlora")
     x = case_input("micro_vda_dvlora").to(cuda)
     set_trainable(model, FACTORS)
@@ -139,7 +141,8 @@ def test_training_forward_is_bit_identical_to_inference(lib, cuda):
     out = model(x)
     assert out[("disp", 0)].requires_grad
     for s in range(4):
-        assert torch.equal(out[("disp", s)].detach(), ref[("disp", s)])
+        a, b = out[("disp", s)].detach(), ref[("disp", s)]
+        assert (a - b).abs().max().item() <= 2e-6 * b.abs().max().item()
 
 
 def test_freeze_schedule_selects_the_gradient_set(lib, cuda):

@@ -125,7 +125,8 @@ def test_lora_grads(lib, cuda, M, nin, nout, r, dv, use_gamma):
         close(o, ref, 1e-5, f"lora d{name}")
 
 
-@pytest.mark.parametrize("Fr,N,heads", [(2, 1370, 6), (1, 64, 2), (3, 10, 1), (1, 129, 12), (2, 321, 6), (9, 200, 3)])
+# (8, 1370, 6): 528 tasks on 512 resident slots = one whole round + 16 tasks split along the streamed axis
+@pytest.mark.parametrize("Fr,N,heads", [(2, 1370, 6), (1, 64, 2), (3, 10, 1), (1, 129, 12), (2, 321, 6), (9, 200, 3), (8, 1370, 6), (40, 300, 16)])
 def test_attn_spatial_bwd(lib, cuda, Fr, N, heads):
     D = heads * 64
     qkv, g = rnd(Fr * N, 3 * D, seed=1, scale=2.0), rnd(Fr * N, D, seed=2)
@@ -148,8 +149,10 @@ def test_attn_spatial_bwd(lib, cuda, Fr, N, heads):
     assert (lse.cpu().double().reshape(Fr, heads, N) - lse_ref).abs().max().item() < 2e-5
     delta = torch.empty(Fr * heads * N, device=cuda)
     dqkv = torch.full((Fr * N, 3 * D), float("nan"), device=cuda)
-    _lib.check(lib.edv_attn_spatial_bwd(qd.data_ptr(), o.data_ptr(), gd.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), Fr, N, heads, st()),
-               "edv_attn_spatial_bwd")
+    nbb = lib.edv_attn_spatial_bwd_workspace(Fr, N, heads)
+    wsb = torch.full((max(nbb // 4, 4),), float("nan"), device=cuda)
+    _lib.check(lib.edv_attn_spatial_bwd(qd.data_ptr(), o.data_ptr(), gd.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), Fr, N, heads,
+                                        wsb.data_ptr(), nbb, st()), "edv_attn_spatial_bwd")
     for j, name in enumerate("qkv"):
         close(dqkv[:, j * D:(j + 1) * D], ref[:, j * D:(j + 1) * D], 1e-5, f"attn_spatial_bwd d{name}")
 

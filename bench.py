@@ -32,6 +32,7 @@ MODELS = {"vits": VITS, "vitb": VITB, "vitl": VITL}
 DIMS = {"vits": (384, 12, 6), "vitb": (768, 12, 12), "vitl": (1024, 24, 16)}
 # matmul+conv FLOPs per 518x518 frame, FlopCounterMode over the reference
 GFLOP_PER_FRAME = {"vits": 121.1, "vitb": 403.9, "vitl": 1403.8}
+LIN_STEPS = 2  # timed steps whose dense-GEMM launches are bracketed with HIP events (see main)
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 
 
@@ -52,10 +53,10 @@ def parse():
     return ap.parse_args()
 
 
-def measured_traffic(encoder, T, image, clips=1):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (collected in
-    their own runs, FETCH_SIZE doubled as the gfx950 guide prescribes); None when no pass matches this workload."""
-    path = os.path.join(ROOT, "profiles", "r01_attn_traffic.json")
+def measured_traffic(encoder, T, image, clips=1, which="gemm"):
+    """HBM-side bytes per launch of a kernel from the committed rocprofv3 --pmc passes (collected in their own runs,
+    FETCH_SIZE doubled as the gfx950 guide prescribes); None when no pass matches this workload."""
+    path = os.path.join(ROOT, "profiles", f"r01_{which}_traffic.json")
     try:
         with open(path) as f:
             rec = json.load(f)
@@ -133,28 +134,48 @@ def main():
         if not args.no_kernel_events:
             model.profile_enable(["attn_spatial"])
         sync_all()
+        # 12 attention calls per step are bracketed throughout; the ~88 linear launches only in the last LIN_STEPS steps of
+        # the timed region: an event pair per launch costs ~5 % of the step when put around every small GEMM of the head.
+        lin_from = args.steps - min(LIN_STEPS, args.steps)
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for i in range(args.steps):
+            if i == lin_from and not args.no_kernel_events:
+                model.profile_set(["attn_spatial", "linear"])
             out = model(x)
         torch.cuda.synchronize(dev)
         parallel.barrier()
         dt = time.perf_counter() - t0
     dt = parallel.max_over_ranks(dt, dev)
 
-    roofline = None
+    # Dominant kernel by time (profiles/r01_i_bench_T8_kernel_stats.csv): gemm_dma_kernel, the dense F.linear / 1x1-conv GEMM
+    # (49 % of the step over its two epilogue variants); second: the encoder attention call (20 %).  Both are bracketed
+    # with HIP event pairs on their launch stream inside the timed region; the engine accounts the algorithmic work of the
+    # bracketed linear launches itself (2 M N K and A, W, C (+ residual) once).
+    roofline = roofline_attn = None
     if not args.no_kernel_events:
+        n_l, ms_l = model.profile_read("linear")
+        fl_l, by_l = model.profile_work("linear")
+        if n_l > 0 and ms_l > 0:
+            achieved = fl_l / (ms_l * 1e-3) / 1e12
+            roofline = {"kernel": "gemm_dma_kernel (every F.linear / 1x1 conv of the step: qkv, proj, fc1, fc2 of the 12 blocks + the head's)",
+                        "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(args.encoder, T, S, Bc, "gemm"),
+                        "traffic_unit": "bytes per launch, mean over the step's launches (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_gemm_traffic.json)",
+                        "algorithmic_bytes_per_launch": round(by_l / n_l, 1), "launches": n_l, "avg_launch_ms": round(ms_l / n_l, 4),
+                        "flop_per_launch": round(fl_l / n_l, 1), "peak_dtype": "f32 MFMA (v_mfma_f32_32x32x2_f32), dense"}
         n, ms = model.profile_read("attn_spatial")
         D, depth, heads = DIMS[args.encoder]
         ntok = (S // 14) ** 2 + 1
         flops = 4.0 * ntok * ntok * 64 * heads * T * Bc  # QK^T + PV, 2 FLOP per MAC, per launch (one encoder block, all frames)
         if n > 0 and ms > 0:
             achieved = flops / (ms / n * 1e-3) / 1e12
-            roofline = {"kernel": "attn_spatial_kernel", "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(args.encoder, T, S, Bc),
-                        "traffic_unit": "bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_attn_traffic.json)",
-                        "algorithmic_bytes_per_launch": 4.0 * ntok * T * Bc * heads * 64 * 4,
-                        "launches": n, "avg_launch_ms": round(ms / n, 4), "flop_per_launch": flops,
-                        "peak_dtype": "f32 MFMA (v_mfma_f32_32x32x2_f32), dense"}
+            roofline_attn = {"kernel": "attn_spatial_kernel + attn_combine_kernel (one encoder-block attention call)", "bound": "mfma",
+                             "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(args.encoder, T, S, Bc, "attn"),
+                             "traffic_unit": "bytes per call (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_attn_traffic.json)",
+                             "algorithmic_bytes_per_launch": 4.0 * ntok * T * Bc * heads * 64 * 4,
+                             "launches": n, "avg_launch_ms": round(ms / n, 4), "flop_per_launch": flops,
+                             "peak_dtype": "f32 MFMA (v_mfma_f32_32x32x2_f32), dense"}
     # PCIe-inclusive variant (never `value`): pinned host clip -> HBM, forward, the four maps -> pinned host
     pcie_value = None
     if world == 1:
@@ -189,7 +210,7 @@ def main():
             "model_tflops": round(GFLOP_PER_FRAME[args.encoder] * (S / 518.0) ** 2 * value / 1e3, 2),
             "launches_per_step": model.launch_count(), "device_mem_mb": round(model.device_bytes() / 2 ** 20, 1), "output_finite": finite,
             "pcie_inclusive_value": None if pcie_value is None else round(pcie_value, 2),
-            "roofline": roofline,
+            "roofline": roofline, "roofline_attention": roofline_attn,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(kwargs, T, S, args.cpu_threads)

@@ -53,6 +53,8 @@ struct edv_ctx {
     edv_config cfg{};
     unsigned prof_mask = 0;
     EvPool prof[KC_COUNT];
+    double prof_flops[KC_COUNT] = {0, 0, 0, 0, 0, 0};  // algorithmic work of the bracketed launches (edv_profile_work)
+    double prof_bytes[KC_COUNT] = {0, 0, 0, 0, 0, 0};
     int enc_streams = 1;                      // 2: run the two halves of the frame batch through the encoder concurrently
     hipStream_t sub[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -166,6 +168,10 @@ struct Run {
         g.A = A; g.lda = K; g.W = W; g.ldw = K; g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K;
         g.bias = bias; g.act = act; g.gamma = gamma; g.R1 = R1; g.ldr1 = N;
         c->launches++;
+        if (c->prof_mask & (1u << KC_LINEAR)) {  // 2 M N K; A, W read once, C written once (+ the residual read)
+            c->prof_flops[KC_LINEAR] += 2.0 * (double)M * N * K;
+            c->prof_bytes[KC_LINEAR] += 4.0 * ((double)M * K + (double)N * K + (double)M * N * (R1 ? 2 : 1));
+        }
         Bracket b_(c, KC_LINEAR, st);
         return gemm_ws(g);
     }
@@ -1546,6 +1552,14 @@ int edv_profile_enable(edv_ctx *ctx, uint32_t class_mask) {
     EDV_CHECK(class_mask < (1u << KC_COUNT), "unknown kernel class in mask");
     ctx->prof_mask = class_mask;
     for (auto &p : ctx->prof) p.used = 0;
+    for (int k = 0; k < KC_COUNT; ++k) ctx->prof_flops[k] = ctx->prof_bytes[k] = 0.0;
+    return 0;
+}
+
+int edv_profile_set_mask(edv_ctx *ctx, uint32_t class_mask) {
+    EDV_CHECK(ctx, "null context");
+    EDV_CHECK(class_mask < (1u << KC_COUNT), "unknown kernel class in mask");
+    ctx->prof_mask = class_mask;  // nothing recorded so far is dropped
     return 0;
 }
 
@@ -1563,6 +1577,15 @@ int edv_profile_read(edv_ctx *ctx, int32_t kernel_class, int32_t *launches, doub
     *launches = (int32_t)p.used;
     *total_ms = sum;
     p.used = 0;
+    return 0;
+}
+
+int edv_profile_work(edv_ctx *ctx, int32_t kernel_class, double *flops, double *bytes) {
+    EDV_CHECK(ctx && flops && bytes, "null argument");
+    EDV_CHECK(kernel_class >= 0 && kernel_class < KC_COUNT, "unknown kernel class");
+    *flops = ctx->prof_flops[kernel_class];
+    *bytes = ctx->prof_bytes[kernel_class];
+    ctx->prof_flops[kernel_class] = ctx->prof_bytes[kernel_class] = 0.0;
     return 0;
 }
 

@@ -616,11 +616,24 @@ class endodav(nn.Module):
             mask |= 1 << _lib.KERNEL_CLASSES[c]
         _lib.check(_lib.load().edv_profile_enable(C.c_void_p(nat.handle), mask), "edv_profile_enable")
 
+    def profile_set(self, classes: Sequence[str]) -> None:
+        """Change the bracketed kernel classes without dropping what was recorded so far."""
+        mask = 0
+        for c in classes:
+            mask |= 1 << _lib.KERNEL_CLASSES[c]
+        _lib.check(_lib.load().edv_profile_set_mask(C.c_void_p(self._last.handle), mask), "edv_profile_set_mask")
+
     def profile_read(self, cls: str) -> Tuple[int, float]:
         """(launches, summed milliseconds) of one kernel class since the last read."""
         n, ms = C.c_int32(), C.c_double()
         _lib.check(_lib.load().edv_profile_read(C.c_void_p(self._last.handle), _lib.KERNEL_CLASSES[cls], C.byref(n), C.byref(ms)), "edv_profile_read")
         return n.value, ms.value
+
+    def profile_work(self, cls: str) -> Tuple[float, float]:
+        """(FLOP, algorithmic bytes) of the launches of one kernel class bracketed since the last read."""
+        fl, by = C.c_double(), C.c_double()
+        _lib.check(_lib.load().edv_profile_work(C.c_void_p(self._last.handle), _lib.KERNEL_CLASSES[cls], C.byref(fl), C.byref(by)), "edv_profile_work")
+        return fl.value, by.value
 
     def device_bytes(self) -> int:
         nat = getattr(self, "_last", None)

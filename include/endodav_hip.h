@@ -98,7 +98,11 @@ int edv_set_capture(edv_ctx *ctx, int on);
  * attention, 3 temporal attention, 4 LayerNorm, 5 other.  edv_profile_read waits for the recorded events,
  * returns the number of launches and their summed duration, and clears that class. */
 int edv_profile_enable(edv_ctx *ctx, uint32_t class_mask);
+int edv_profile_set_mask(edv_ctx *ctx, uint32_t class_mask); /* change the bracketed classes, keep what was recorded */
 int edv_profile_read(edv_ctx *ctx, int32_t kernel_class, int32_t *launches, double *total_ms);
+/* Algorithmic work of the launches bracketed since edv_profile_enable / the last call (class 0, linear: 2 M N K FLOP and
+ * 4 (M K + N K + M N (+ M N residual)) bytes per launch; 0 for classes that do not account). */
+int edv_profile_work(edv_ctx *ctx, int32_t kernel_class, double *flops, double *bytes);
 /* Bytes of device memory the context currently holds (packed weights + workspace). */
 size_t edv_device_bytes(const edv_ctx *ctx);
 /* Seconds spent in the dominant kernels are measured by the caller with HIP events; this

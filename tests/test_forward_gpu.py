@@ -186,6 +186,22 @@ def test_weights_update_is_seen(cuda):
     assert (out1[("disp", 0)] - out0[("disp", 0)]).abs().max() > 0
 
 
+def test_changing_clip_geometry_between_calls(cuda):
+    """Workspace buffers grow and the head's internal stream is re-used across calls with different T and B: every call
+    must give what a fresh model gives for that clip."""
+    model, kwargs, x, _ = run_hip("micro_vda_dvlora", cuda)  # [1, 3, 3, 42, 56]
+    torch.manual_seed(0)
+    clips = [torch.rand(1, 2, 3, 42, 56, device=cuda), torch.rand(2, 5, 3, 42, 56, device=cuda), torch.rand(1, 20, 3, 42, 56, device=cuda),
+             torch.rand(1, 2, 3, 42, 56, device=cuda)]
+    with torch.no_grad():
+        got = [{k: v.clone() for k, v in model(c).items()} for c in clips]
+        for c, g in zip(clips, got):
+            fresh, _, _, _ = run_hip("micro_vda_dvlora", cuda)
+            ref = fresh(c)
+            for k in ref:
+                assert torch.equal(ref[k], g[k]), (tuple(c.shape), k)
+
+
 def test_survives_dataparallel_wrapper(cuda):
     """The trainer wraps the depth model in nn.DataParallel (trainer_end_to_end_video.py:269-271, --use_dp) and still
     reaches .module.state_dict() / infer through it; with one visible device the wrapper calls the module directly."""

@@ -71,6 +71,7 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const float *__res
     const int n = P * cg;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float s = 0.f;
+#pragma unroll 8  // the slab is L2-resident and the loop is one dependent load per trip: keep several in flight
     for (int i = threadIdx.x; i < n; i += 256) {
         const int p = i / cg, c = i - p * cg;
         s += xf[(long long)p * C + c];
@@ -82,6 +83,7 @@ __global__ __launch_bounds__(256) void groupnorm_stats_kernel(const float *__res
     __syncthreads();
     const float mean = bc;
     float q = 0.f;
+#pragma unroll 8
     for (int i = threadIdx.x; i < n; i += 256) {
         const int p = i / cg, c = i - p * cg;
         const float d = xf[(long long)p * C + c] - mean;

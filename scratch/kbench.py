@@ -104,7 +104,7 @@ elif __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "sweep":
         gemm(M, 384, 384, res=True, label=f"proj T{T}")
         gemm(M, 384, 1536, res=True, label=f"fc2 T{T}")
         attn(T, 1370, 6)
-elif __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("attnbwd", "tattn", "head")):
+elif __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("attnbwd", "tattn", "head", "gn")):
     M = 8 * 1370
     gemm(M, 1152, 384, label="qkv")
     gemm(M, 1536, 384, act=1, label="fc1+gelu")
@@ -164,3 +164,11 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "head":
     gemm(10952, 384, 96, label="convT2")
     for (M, tag) in ((2888, "oc4"), (10952, "oc3"), (43808, "oc2"), (175232, "oc1")):
         gemm(M, 64, 64, label=tag)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "gn":
+    for (F_, P, Cc) in ((8, 1369, 192), (8, 361, 384), (8, 1369, 64), (8, 5476, 64)):
+        x = torch.randn(F_, P, Cc, device=dev); w = torch.randn(Cc, device=dev); b = torch.randn(Cc, device=dev)
+        y = torch.empty_like(x); stats = torch.empty(F_ * 64, device=dev)
+        t = timeit(lambda: _lib.check(lib.edv_groupnorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), F_, P, Cc, 32, 1e-6, st())))
+        print(f"groupnorm F={F_} P={P} C={Cc}: {t*1e6:7.1f} us (stats + apply)  {x.numel()*4*2/t/1e12:5.2f} TB/s", flush=True)

@@ -340,6 +340,7 @@ __global__ __launch_bounds__(256) void groupnorm_bwd_sums_kernel(const float *__
     const float mean = stats[((long long)f * groups + g) * 2], rstd = stats[((long long)f * groups + g) * 2 + 1];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float s1 = 0.f, s2 = 0.f;
+#pragma unroll 8  // L2-resident slab, one dependent load pair per trip: keep several in flight
     for (int i = threadIdx.x; i < n; i += 256) {
         const int p = i / cg, c = i - p * cg;
         const long long o = base + (long long)p * C + c;

@@ -134,6 +134,34 @@ def test_baseline_config_vits_518_t8_against_oracle(cuda):
         assert e <= DISP_RTOL and de <= DEPTH_RTOL and ar <= ABS_REL_MAX
 
 
+def test_clips_are_independent_at_full_size(cuda):
+    """Size-independent property at BASELINE's full size (no oracle run needed): forward never mixes clips, so a
+    batch of two 518x518 T=8 clips equals the two clips run alone -- up to summation order only, because the split of the
+    attention's last partial round depends on how many frames a launch holds."""
+    import endodav_amd
+    from endodav_amd import synth
+
+    kwargs = dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384], image_shape=(518, 518), lora_type="dvlora", disable_conv_head=True)
+    model = endodav_amd.endodav(**kwargs).eval()
+    synth.fill_module_(model)
+    model = model.to(cuda)
+    x = torch.from_numpy(synth.synth_clip(2, 8, 518, 518, seed=4, kind="tissue")).to(cuda)
+    with torch.no_grad():
+        both = {k: v.clone() for k, v in model(x).items()}
+        for b in range(2):
+            one = model(x[b:b + 1])
+            for s in range(4):
+                ref = one[("disp", s)]
+                got = both[("disp", s)][8 * b:8 * (b + 1)]
+                assert (got - ref).abs().max().item() <= 5e-6 * ref.abs().max().item(), (b, s)
+    # and a permutation of the clips permutes the outputs
+    with torch.no_grad():
+        swapped = model(x.flip(0))
+    for s in range(4):
+        a, b_ = swapped[("disp", s)], torch.cat([both[("disp", s)][8:], both[("disp", s)][:8]])
+        assert (a - b_).abs().max().item() <= 5e-6 * b_.abs().max().item()
+
+
 @pytest.mark.parametrize("encoder,features,out_channels,T", [("vitb", 128, [96, 192, 384, 768], 2), ("vitl", 256, [256, 512, 1024, 1024], 1)])
 def test_larger_encoders_full_size_against_oracle(cuda, encoder, features, out_channels, T):
     """BASELINE configs 3 and 5 use ViT-B / ViT-L at 518x518: full-size parity against the CPU oracle.  (ViT-L goes

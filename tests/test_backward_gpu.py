@@ -163,6 +163,30 @@ def test_freeze_schedule_selects_the_gradient_set(lib, cuda):
                 assert p.grad is None, n
 
 
+def test_gradient_is_linear_in_the_upstream_gradient_at_full_size(lib, cuda):
+    """Size-independent property at BASELINE's full size (ViT-S 518x518 T=8, no oracle run): the backward is a linear map of
+    dL/d disp.  Doubling the upstream gradient doubles every factor gradient bit for bit (a power of two commutes with
+    rounding); the gradient of a sum is the sum of the gradients up to summation order."""
+    kwargs = dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384], image_shape=(518, 518), lora_type="dvlora", disable_conv_head=True)
+    model = endodav_amd.endodav(**kwargs, pretrained_path=None)
+    synth.fill_module_(model)
+    names = set_trainable(model, FACTORS)
+    x = torch.from_numpy(synth.synth_clip(1, 8, 518, 518, seed=6, kind="tissue"))
+    model = model.to(cuda).train()
+    shapes = [(8, 1, h, w) for (h, w) in model.output_shapes()]
+    ga, gb = upstream(shapes, seed=5), upstream(shapes, seed=9, signed=True)
+    clone = lambda d: {n: g.clone() for n, g in d.items()}
+    g1 = clone(hip_grads(model, x, names, ga, cuda)[0])
+    g2 = clone(hip_grads(model, x, names, [2.0 * g for g in ga], cuda)[0])
+    g3 = clone(hip_grads(model, x, names, gb, cuda)[0])
+    g4 = clone(hip_grads(model, x, names, [a + b for a, b in zip(ga, gb)], cuda)[0])
+    for n in names:
+        assert torch.isfinite(g1[n]).all() and g1[n].abs().max() > 0, n
+        assert torch.equal(g2[n], 2.0 * g1[n]), n
+        ref = g1[n] + g3[n]
+        assert (g4[n] - ref).abs().max().item() <= 2e-5 * max(ref.abs().max().item(), g1[n].abs().max().item()), n
+
+
 def test_temporal_only_phase_stops_at_the_head(lib, cuda):
     """The trainer's temporal tuning phase (trainer_end_to_end_video.py:327-339): only ff.net.2 factors are trainable, the
     backward does not enter the encoder, and the gradients equal those of a full backward."""

@@ -132,19 +132,24 @@ def main():
             out = model(x)
         sync_all()
         if not args.no_kernel_events:
-            model.profile_enable(["attn_spatial"])
+            model.profile_enable([])
         sync_all()
-        # 12 attention calls per step are bracketed throughout; the ~88 linear launches only in the last LIN_STEPS steps of
-        # the timed region: an event pair per launch costs ~5 % of the step when put around every small GEMM of the head.
+        # Kernel timing happens inside the timed region, in its last LIN_STEPS steps: there every dense-GEMM launch and every
+        # attention call is bracketed with a HIP event pair on its launch stream, and the encoder runs single-stream so that a
+        # bracket times the kernel alone (by default the engine overlaps two frame groups on internal streams for short
+        # clips, which is what the other steps run).  Event pairs around ~100 launches cost ~5 % of those steps.
         lin_from = args.steps - min(LIN_STEPS, args.steps)
         t0 = time.perf_counter()
         for i in range(args.steps):
             if i == lin_from and not args.no_kernel_events:
+                model.set_encoder_streams(1)
                 model.profile_set(["attn_spatial", "linear"])
             out = model(x)
         torch.cuda.synchronize(dev)
         parallel.barrier()
         dt = time.perf_counter() - t0
+        if not args.no_kernel_events:
+            model.set_encoder_streams(0)
     dt = parallel.max_over_ranks(dt, dev)
 
     # Dominant kernel by time (profiles/r01_i_bench_T8_kernel_stats.csv): gemm_dma_kernel, the dense F.linear / 1x1-conv GEMM

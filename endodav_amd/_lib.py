@@ -61,6 +61,7 @@ SIGNATURES = {
     "edv_stage_copy": (C.c_int, [C.c_void_p, C.c_char_p, _fp, C.POINTER(C.c_size_t), C.c_void_p]),
     "edv_set_capture": (C.c_int, [C.c_void_p, C.c_int]),
     "edv_profile_enable": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "edv_set_encoder_streams": (C.c_int, [C.c_void_p, _i32]),
     "edv_profile_set_mask": (C.c_int, [C.c_void_p, C.c_uint32]),
     "edv_profile_work": (C.c_int, [C.c_void_p, _i32, C.POINTER(_f64), C.POINTER(_f64)]),
     "edv_profile_read": (C.c_int, [C.c_void_p, _i32, C.POINTER(_i32), C.POINTER(_f64)]),

@@ -55,7 +55,7 @@ struct edv_ctx {
     EvPool prof[KC_COUNT];
     double prof_flops[KC_COUNT] = {0, 0, 0, 0, 0, 0};  // algorithmic work of the bracketed launches (edv_profile_work)
     double prof_bytes[KC_COUNT] = {0, 0, 0, 0, 0, 0};
-    int enc_streams = 1;                      // 2: run the two halves of the frame batch through the encoder concurrently
+    int enc_streams = 0;                      // 0: automatic (2 for small clips); n >= 1: that many frame groups on internal streams
     hipStream_t sub[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_x[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // cross-stream edges of the head (r3, r1r2, u3, u2, u1)
@@ -700,7 +700,12 @@ struct Run {
         // Frames are independent in the encoder: with two internal streams the two halves of the batch run as
         // concurrent kernels, so workgroups of different kernels (one half's attention, the other's GEMM) co-reside
         // on the CUs and fill each other's stalls and grid tails.  The head needs all T frames again (temporal attention).
-        int nstreams = (c->enc_streams > 1 && !c->capture) ? (c->enc_streams > 4 ? 4 : c->enc_streams) : 1;
+        // Automatic: two frame groups while a block's GEMMs are short (tokens x width <= 12 M: ViT-S up to T=16) -- one group's
+        // attention then runs beside the other group's GEMMs and fills their launch ramps and drains.  Measured, 2 vs 1 streams:
+        // ViT-S T=4 +2.7 %, T=8 +4.8 %, T=16 +2.4 %, T=32 +1.3 %; ViT-B T=16 +-0; ViT-L T=32 -1.3 % (profiles/r01_gemm_tile_sweep.txt).
+        int want = c->enc_streams;
+        if (want <= 0) want = (MT * (long long)D <= 12000000ll) ? 2 : 1;
+        int nstreams = (want > 1 && !c->capture && !c->train) ? (want > 4 ? 4 : want) : 1;
         if (nstreams > F) nstreams = F;
         size_t attws_each = 0;  // the largest split workspace any stream's share of the frames needs
         for (int h = 0, f0 = 0; h < nstreams; ++h) {
@@ -1472,7 +1477,6 @@ int edv_forward(edv_ctx *ctx, const float *x_dev, int32_t B, int32_t T, int32_t 
         EDV_CHECK(!ctx->capture, "stage capture and training are exclusive");
     }
     Run r(ctx, (hipStream_t)stream);
-    if (ctx->train) ctx->enc_streams = 1;  // the saved activations are per block, not per stream
     const int rc = r.forward(x_dev, B, T, H, W, disp_dev);
     ctx->have_saved = rc == 0 && ctx->train;
     return rc;
@@ -1482,6 +1486,13 @@ int edv_set_train(edv_ctx *ctx, int32_t on) {
     EDV_CHECK(ctx, "null context");
     ctx->train = on != 0;
     if (!ctx->train) ctx->have_saved = false;
+    return 0;
+}
+
+int edv_set_encoder_streams(edv_ctx *ctx, int32_t n) {
+    EDV_CHECK(ctx, "null context");
+    EDV_CHECK(n >= 0 && n <= 4, "encoder streams: 0 (automatic) .. 4");
+    ctx->enc_streams = n;
     return 0;
 }
 

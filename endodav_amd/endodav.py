@@ -616,6 +616,10 @@ class endodav(nn.Module):
             mask |= 1 << _lib.KERNEL_CLASSES[c]
         _lib.check(_lib.load().edv_profile_enable(C.c_void_p(nat.handle), mask), "edv_profile_enable")
 
+    def set_encoder_streams(self, n: int) -> None:
+        """0 = automatic (default), 1..4 = that many frame groups on internal streams (see ``edv_set_encoder_streams``)."""
+        _lib.check(_lib.load().edv_set_encoder_streams(C.c_void_p(self._last.handle), int(n)), "edv_set_encoder_streams")
+
     def profile_set(self, classes: Sequence[str]) -> None:
         """Change the bracketed kernel classes without dropping what was recorded so far."""
         mask = 0

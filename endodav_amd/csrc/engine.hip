@@ -700,11 +700,11 @@ struct Run {
         // Frames are independent in the encoder: with two internal streams the two halves of the batch run as
         // concurrent kernels, so workgroups of different kernels (one half's attention, the other's GEMM) co-reside
         // on the CUs and fill each other's stalls and grid tails.  The head needs all T frames again (temporal attention).
-        // Automatic: two frame groups while a block's GEMMs are short (tokens x width <= 12 M: ViT-S up to T=16) -- one group's
+        // Automatic: two frame groups while a block's GEMMs are short (tokens x width <= 17 M: ViT-S up to T=32, ViT-B up to T=16) -- one group's
         // attention then runs beside the other group's GEMMs and fills their launch ramps and drains.  Measured, 2 vs 1 streams:
         // ViT-S T=4 +2.7 %, T=8 +4.8 %, T=16 +2.4 %, T=32 +1.3 %; ViT-B T=16 +-0; ViT-L T=32 -1.3 % (profiles/r01_gemm_tile_sweep.txt).
         int want = c->enc_streams;
-        if (want <= 0) want = (MT * (long long)D <= 12000000ll) ? 2 : 1;
+        if (want <= 0) want = (MT * (long long)D <= 17000000ll) ? 2 : 1;
         int nstreams = (want > 1 && !c->capture && !c->train) ? (want > 4 ? 4 : want) : 1;
         if (nstreams > F) nstreams = F;
         size_t attws_each = 0;  // the largest split workspace any stream's share of the frames needs

@@ -149,7 +149,7 @@ def main():
         parallel.barrier()
         dt = time.perf_counter() - t0
         if not args.no_kernel_events:
-            model.set_encoder_streams(0)
+            model.set_encoder_streams(-1)
     dt = parallel.max_over_ranks(dt, dev)
 
     # Dominant kernel by time (profiles/r01_i_bench_T8_kernel_stats.csv): gemm_dma_kernel, the dense F.linear / 1x1-conv GEMM

@@ -56,6 +56,7 @@ struct edv_ctx {
     double prof_flops[KC_COUNT] = {0, 0, 0, 0, 0, 0};  // algorithmic work of the bracketed launches (edv_profile_work)
     double prof_bytes[KC_COUNT] = {0, 0, 0, 0, 0, 0};
     int enc_streams = 0;                      // 0: automatic (2 for small clips); n >= 1: that many frame groups on internal streams
+    int enc_streams_initial = 0;              // what EDV_ENC_STREAMS asked for at edv_create (edv_set_encoder_streams(-1) restores it)
     hipStream_t sub[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_x[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // cross-stream edges of the head (r3, r1r2, u3, u2, u1)
@@ -1409,7 +1410,7 @@ int edv_create(const edv_config *cfg, edv_ctx **out) {
     for (int j = 0; j < 4; ++j) EDV_CHECK(cfg->taps[j] >= 0 && cfg->taps[j] < cfg->depth && (j == 0 || cfg->taps[j] > cfg->taps[j - 1]), "taps");
     *out = new edv_ctx();
     (*out)->cfg = *cfg;
-    if (const char *e = getenv("EDV_ENC_STREAMS")) (*out)->enc_streams = atoi(e);
+    if (const char *e = getenv("EDV_ENC_STREAMS")) (*out)->enc_streams = (*out)->enc_streams_initial = atoi(e);
     return 0;
 }
 
@@ -1491,8 +1492,8 @@ int edv_set_train(edv_ctx *ctx, int32_t on) {
 
 int edv_set_encoder_streams(edv_ctx *ctx, int32_t n) {
     EDV_CHECK(ctx, "null context");
-    EDV_CHECK(n >= 0 && n <= 4, "encoder streams: 0 (automatic) .. 4");
-    ctx->enc_streams = n;
+    EDV_CHECK(n >= -1 && n <= 4, "encoder streams: -1 (initial setting), 0 (automatic), 1 .. 4");
+    ctx->enc_streams = n < 0 ? ctx->enc_streams_initial : n;
     return 0;
 }
 

@@ -617,7 +617,8 @@ class endodav(nn.Module):
         _lib.check(_lib.load().edv_profile_enable(C.c_void_p(nat.handle), mask), "edv_profile_enable")
 
     def set_encoder_streams(self, n: int) -> None:
-        """0 = automatic (default), 1..4 = that many frame groups on internal streams (see ``edv_set_encoder_streams``)."""
+        """0 = automatic, 1..4 = that many frame groups on internal streams, -1 = the initial setting (automatic unless
+        EDV_ENC_STREAMS was set) -- see ``edv_set_encoder_streams``."""
         _lib.check(_lib.load().edv_set_encoder_streams(C.c_void_p(self._last.handle), int(n)), "edv_set_encoder_streams")
 
     def profile_set(self, classes: Sequence[str]) -> None:

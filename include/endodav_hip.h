@@ -101,7 +101,7 @@ int edv_profile_enable(edv_ctx *ctx, uint32_t class_mask);
 /* Frames are independent in the encoder.  n = 0 (default): automatic -- two frame groups on internal streams while a block's
  * GEMMs are short (tokens x width <= 17 M: ViT-S up to T = 32, ViT-B up to T = 16), one otherwise; n = 1..4: that many.  With more than one group the attention of one
  * group runs beside the GEMMs of another, so per-kernel event brackets then measure time-shared launches: set 1 for the
- * steps whose kernels are being timed (bench.py does).  Environment EDV_ENC_STREAMS sets the initial value. */
+ * steps whose kernels are being timed (bench.py does).  Environment EDV_ENC_STREAMS sets the initial value; n = -1 restores it. */
 int edv_set_encoder_streams(edv_ctx *ctx, int32_t n);
 int edv_profile_set_mask(edv_ctx *ctx, uint32_t class_mask); /* change the bracketed classes, keep what was recorded */
 int edv_profile_read(edv_ctx *ctx, int32_t kernel_class, int32_t *launches, double *total_ms);

@@ -156,6 +156,7 @@ struct Run {
     int pk(const std::string &name, size_t n, float **out) { return alloc_buf(c, c->packed, name, n, st, out); }
 
     // ---- op wrappers ----------------------------------------------------------------------
+    bool stagger_record = false;  // encoder_range records ev_x[5] after block 0's qkv GEMM (start signal for the next frame group)
     float *skws = nullptr;  // stream-K split workspace of the stream this Run is enqueueing on
     size_t skws_floats = 0;
     int gemm_ws(GemmDesc &g) {
@@ -633,6 +634,7 @@ struct Run {
             EDV_TRY(param(bp + ".attn.qkv.weight", &w));
             EDV_TRY(param(bp + ".attn.qkv.bias", &b));
             EDV_TRY(linear(xn, MT, D, w, 3 * D, b, qkv));
+            if (i == 0 && stagger_record) EDV_HIP(hipEventRecord(c->ev_x[5], st));  // the next frame group may start
             {
                 Bracket b_(c, KC_ATTN_SPATIAL, st);
                 EDV_TRY(attn_spatial(qkv, att, F, ntok, heads, eb.attws + (size_t)lane * eb.attws_each, eb.attws_each, st, lse));
@@ -740,9 +742,18 @@ struct Run {
             hipStream_t user = st;
             EDV_HIP(hipEventRecord(c->ev_fork, user));
             int f0 = 0;
+            static const bool stagger = [] {
+                const char *e = getenv("EDV_ENC_STAGGER");  // 0: the groups start together (A/B runs)
+                return !(e && atoi(e) == 0);
+            }();
             for (int h = 0; h < nstreams; ++h) {
                 const int nf = (Fall - f0) / (nstreams - h);  // even split of the remaining frames
                 EDV_HIP(hipStreamWaitEvent(c->sub[h], c->ev_fork, 0));
+                // Group h starts when group h-1 has launched its first attention: the groups then run half a block apart, so
+                // one group's attention (2 workgroups per CU, MFMA-bound) runs beside the other's GEMM ramps and drains
+                // instead of beside its own kind.
+                if (stagger && h > 0) EDV_HIP(hipStreamWaitEvent(c->sub[h], c->ev_x[5], 0));
+                stagger_record = stagger && h + 1 < nstreams;
                 const int rc = encoder_range(eb, x, f0, nf, H, W, c->sub[h], h);
                 st = user; F = Fall; skws = skws_all;
                 if (rc) return rc;

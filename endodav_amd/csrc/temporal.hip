@@ -143,57 +143,62 @@ __global__ __launch_bounds__(256) void attn_temporal_small_kernel(const float *_
     }
 }
 
-// Wide channels (d = C/8 >= 24) at T <= 8: one 64-thread workgroup per (clip, pixel).  The pixel's T rows of q|k|v
-// (T * 3C floats, <= 36 KB at C = 384) are fetched with ONE round of coalesced loads into LDS; thread (query tq, head) then
-// works out of LDS.  The per-thread kernels above chain 24 dependent load batches per thread when d = 48 and there are only
-// B * P * 8 = 2888 threads to hide them behind (50 us per call for 18 MB of traffic).
-__global__ __launch_bounds__(64) void attn_temporal_pixel_kernel(const float *__restrict__ qkv, float *__restrict__ out, int T, int P, int C, int heads,
-                                                                  float scale) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // [T][3C]
-    const int tid = threadIdx.x;
-    const int b = blockIdx.x / P, p = blockIdx.x - b * P;
-    const int C3 = 3 * C, n4 = C3 >> 2;
-    for (int idx = tid; idx < T * n4; idx += 64) {
-        const int t = idx / n4, c4 = idx - t * n4;
-        *reinterpret_cast<f32x4 *>(&sm[t * C3 + 4 * c4]) = *reinterpret_cast<const f32x4 *>(qkv + ((long long)(b * T + t) * P + p) * C3 + 4 * c4);
+// One workgroup per (clip, pixel, group of HG heads): the T rows of that pixel's q|k|v slice are fetched with ONE round of
+// coalesced loads into LDS (T * 3 * HG * d floats); thread (query tq, head) then works out of LDS.  The per-thread kernels
+// above chain dozens of dependent load batches per thread when d = 48 and have only B * P * 8 threads to hide them behind
+// (50 us per call for 18 MB of traffic at T = 8; 795 us per call at ViT-B T = 16 with the per-query kernel).
+template <int TMAX>
+__global__ __launch_bounds__(256) void attn_temporal_pixel_kernel(const float *__restrict__ qkv, float *__restrict__ out, int T, int P, int C, int heads,
+                                                                   int HG, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [T][3][HG * d]
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int ngroups = heads / HG;
+    const int hg = blockIdx.x % ngroups;
+    const long long bp = blockIdx.x / ngroups;
+    const int b = (int)(bp / P), p = (int)(bp - (long long)b * P);
+    const int d = C / heads, C3 = 3 * C, W = HG * d, w4 = W >> 2;
+    for (int idx = tid; idx < T * 3 * w4; idx += nthr) {
+        const int t = idx / (3 * w4), r = idx - t * 3 * w4;
+        const int part = r / w4, c4 = r - part * w4;
+        *reinterpret_cast<f32x4 *>(&sm[(t * 3 + part) * W + 4 * c4]) =
+            *reinterpret_cast<const f32x4 *>(qkv + ((long long)(b * T + t) * P + p) * C3 + part * C + hg * W + 4 * c4);
     }
     __syncthreads();
-    const int head = tid % heads, tq = tid / heads;
+    const int hl = tid % HG, tq = tid / HG;
     if (tq >= T) return;
-    const int d = C / heads;
-    const float *q = sm + tq * C3 + head * d;
-    float s[8];
+    const float *q = sm + (tq * 3 + 0) * W + hl * d;
+    float s[TMAX];
 #pragma unroll
-    for (int ts = 0; ts < 8; ++ts) s[ts] = 0.f;
+    for (int ts = 0; ts < TMAX; ++ts) s[ts] = 0.f;
     for (int c = 0; c < d; c += 4) {
         const f32x4 q4 = *reinterpret_cast<const f32x4 *>(q + c);
 #pragma unroll
-        for (int ts = 0; ts < 8; ++ts)
+        for (int ts = 0; ts < TMAX; ++ts)
             if (ts < T) {
-                const f32x4 k4 = *reinterpret_cast<const f32x4 *>(sm + ts * C3 + C + head * d + c);
+                const f32x4 k4 = *reinterpret_cast<const f32x4 *>(sm + (ts * 3 + 1) * W + hl * d + c);
                 s[ts] += (q4.x * k4.x + q4.y * k4.y) + (q4.z * k4.z + q4.w * k4.w);
             }
     }
     float mx = -INFINITY;
 #pragma unroll
-    for (int ts = 0; ts < 8; ++ts)
+    for (int ts = 0; ts < TMAX; ++ts)
         if (ts < T) {
             s[ts] *= scale;
             mx = fmaxf(mx, s[ts]);
         }
     float sum = 0.f;
 #pragma unroll
-    for (int ts = 0; ts < 8; ++ts) {
+    for (int ts = 0; ts < TMAX; ++ts) {
         s[ts] = ts < T ? expf(s[ts] - mx) : 0.f;
         sum += s[ts];
     }
     const float inv = 1.0f / sum;
-    float *op = out + ((long long)(b * T + tq) * P + p) * C + head * d;
+    float *op = out + ((long long)(b * T + tq) * P + p) * C + (hg * HG + hl) * d;
     for (int c = 0; c < d; c += 4) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ts = 0; ts < 8; ++ts)
-            if (ts < T) acc += s[ts] * *reinterpret_cast<const f32x4 *>(sm + ts * C3 + 2 * C + head * d + c);
+        for (int ts = 0; ts < TMAX; ++ts)
+            if (ts < T) acc += s[ts] * *reinterpret_cast<const f32x4 *>(sm + (ts * 3 + 2) * W + hl * d + c);
         *reinterpret_cast<f32x4 *>(op + c) = acc * inv;
     }
 }
@@ -226,9 +231,21 @@ int attn_temporal(const float *qkv, float *out, int B, int T, int P, int C, int 
         const char *e = getenv("EDV_TATTN_PER_QUERY");  // 1: the one-thread-per-query kernel also for T <= 8 (A/B runs)
         return e && atoi(e) != 0;
     }();
-    if (T <= 8 && !per_query && heads == 8 && C / heads >= 24 && (size_t)T * 3 * C * sizeof(float) <= 64 * 1024 && (long long)B * P < (1ll << 31)) {
-        hipLaunchKernelGGL(attn_temporal_pixel_kernel, dim3((unsigned)(B * P)), dim3(64), (size_t)T * 3 * C * sizeof(float), st, qkv, out, T, P, C, heads,
-                           scale);
+    // pixel-per-workgroup kernel: wide heads at T <= 8, everything at T > 8 (the all-queries-per-thread kernel needs T x T registers)
+    const int d = C / heads;
+    int HG = heads;  // heads per workgroup: as many as fit 256 threads and 64 KB of LDS
+    while (HG > 1 && ((long long)T * HG > 256 || (size_t)T * 3 * HG * d * sizeof(float) > 64 * 1024 || heads % HG != 0)) --HG;
+    const bool pixel_fits = (long long)T * HG <= 256 && (size_t)T * 3 * HG * d * sizeof(float) <= 64 * 1024 && (long long)B * P * (heads / HG) < (1ll << 31);
+    if (!per_query && pixel_fits && (T > 8 || d >= 24)) {
+        const dim3 g3((unsigned)((long long)B * P * (heads / HG)));
+        const dim3 b3((unsigned)(((T * HG + 63) / 64) * 64));
+        const size_t lds = (size_t)T * 3 * HG * d * sizeof(float);
+        if (T <= 8)
+            hipLaunchKernelGGL(attn_temporal_pixel_kernel<8>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
+        else if (T <= 16)
+            hipLaunchKernelGGL(attn_temporal_pixel_kernel<16>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
+        else
+            hipLaunchKernelGGL(attn_temporal_pixel_kernel<32>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
     } else if (T <= 8 && !per_query) {
         const long long tot = (long long)B * P * heads;
         const dim3 g2((unsigned)((tot + 255) / 256));

@@ -104,7 +104,7 @@ elif __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "sweep":
         gemm(M, 384, 384, res=True, label=f"proj T{T}")
         gemm(M, 384, 1536, res=True, label=f"fc2 T{T}")
         attn(T, 1370, 6)
-elif __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("attnbwd", "tattn", "head", "gn")):
+elif __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("attnbwd", "tattn", "head", "gn", "tattn16")):
     M = 8 * 1370
     gemm(M, 1152, 384, label="qkv")
     gemm(M, 1536, 384, act=1, label="fc1+gelu")
@@ -172,3 +172,10 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "gn":
         y = torch.empty_like(x); stats = torch.empty(F_ * 64, device=dev)
         t = timeit(lambda: _lib.check(lib.edv_groupnorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), F_, P, Cc, 32, 1e-6, st())))
         print(f"groupnorm F={F_} P={P} C={Cc}: {t*1e6:7.1f} us (stats + apply)  {x.numel()*4*2/t/1e12:5.2f} TB/s", flush=True)
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "tattn16":
+    import os
+    print("EDV_TATTN_PER_QUERY", os.environ.get("EDV_TATTN_PER_QUERY"))
+    tattn(1, 16, 1369, 384); tattn(1, 16, 361, 768); tattn(1, 16, 1369, 128); tattn(1, 16, 5476, 128)
+    tattn(1, 32, 1369, 1024); tattn(1, 32, 361, 1024); tattn(1, 32, 1369, 256); tattn(1, 32, 5476, 256); tattn(1, 32, 5476, 64)

@@ -298,7 +298,8 @@ def test_attn_spatial_peaked_rows(lib, cuda):
 
 # T <= 8: all-queries-per-thread kernel (d = C/8 < 24) or pixel-per-workgroup kernel (d >= 24); T > 8: per-query kernel
 @pytest.mark.parametrize("Bc,T,P,Cc", [(1, 8, 37 * 37, 192), (2, 3, 50, 64), (1, 16, 19 * 19, 384), (1, 32, 41, 32), (1, 1, 9, 64), (2, 32, 30, 256),
-                                       (1, 8, 19 * 19, 384), (2, 5, 100, 192), (1, 8, 74 * 74, 64), (3, 4, 77, 64), (1, 1, 33, 384)])
+                                       (1, 8, 19 * 19, 384), (2, 5, 100, 192), (1, 8, 74 * 74, 64), (3, 4, 77, 64), (1, 1, 33, 384),
+                                       (1, 16, 19 * 19, 768), (1, 16, 300, 128), (1, 32, 100, 1024), (1, 32, 200, 256), (2, 12, 50, 512)])
 def test_attn_temporal(lib, cuda, Bc, T, P, Cc):
     heads, d = 8, Cc // 8
     qkv = rnd(Bc * T * P, 3 * Cc, seed=1, scale=1.5)

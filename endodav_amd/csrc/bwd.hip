@@ -464,96 +464,101 @@ __global__ __launch_bounds__(64) void attn_temporal_bwd_kernel(const float *__re
     }
 }
 
-// T <= 8, 8 heads: one 64-thread workgroup per (clip, pixel), everything out of LDS (the forward's attn_temporal_pixel_kernel).
-// The pixel's T rows of q|k|v and of dO are fetched with one round of coalesced loads; thread (t, head) first acts as query
-// t (scores, P, dS, dQ), publishes its P and dS rows, then acts as key t (dK = sum_q dS[q][t] Q[q], dV = sum_q P[q][t] dO[q]).
-__global__ __launch_bounds__(64) void attn_temporal_bwd_pixel_kernel(const float *__restrict__ qkv, const float *__restrict__ dout, float *__restrict__ dqkv,
-                                                                      int T, int P, int C, int heads, float scale) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];  // [T][3C] q|k|v, [T][C] dO, [heads][T][8] P, [heads][T][8] dS
-    const int tid = threadIdx.x;
-    const int b = blockIdx.x / P, p = blockIdx.x - b * P;
-    const int C3 = 3 * C, n3 = C3 >> 2, n1 = C >> 2;
-    float *sG = sm + T * C3, *sP = sG + T * C, *sS = sP + heads * T * 8;
-    for (int idx = tid; idx < T * n3; idx += 64) {
-        const int t = idx / n3, c4 = idx - t * n3;
-        *reinterpret_cast<f32x4 *>(&sm[t * C3 + 4 * c4]) = *reinterpret_cast<const f32x4 *>(qkv + ((long long)(b * T + t) * P + p) * C3 + 4 * c4);
+// One workgroup per (clip, pixel, group of HG heads), everything out of LDS (the forward's attn_temporal_pixel_kernel).  The
+// T rows of that pixel's q|k|v slice and of dO are fetched with one round of coalesced loads; thread (t, head) first acts as
+// query t (scores, P, dS, dQ), publishes its P and dS rows, then acts as key t (dK = sum_q dS[q][t] Q[q], dV = sum_q P[q][t] dO[q]).
+template <int TMAX>
+__global__ __launch_bounds__(256) void attn_temporal_bwd_pixel_kernel(const float *__restrict__ qkv, const float *__restrict__ dout, float *__restrict__ dqkv,
+                                                                       int T, int P, int C, int heads, int HG, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];  // [T][3][W] q|k|v, [T][W] dO, [HG][T][TMAX] P, [HG][T][TMAX] dS;  W = HG * d
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int ngroups = heads / HG;
+    const int hg = blockIdx.x % ngroups;
+    const long long bp = blockIdx.x / ngroups;
+    const int b = (int)(bp / P), p = (int)(bp - (long long)b * P);
+    const int d = C / heads, C3 = 3 * C, W = HG * d, w4 = W >> 2;
+    float *sG = sm + T * 3 * W, *sP = sG + T * W, *sS = sP + HG * T * TMAX;
+    for (int idx = tid; idx < T * 3 * w4; idx += nthr) {
+        const int t = idx / (3 * w4), r = idx - t * 3 * w4;
+        const int part = r / w4, c4 = r - part * w4;
+        *reinterpret_cast<f32x4 *>(&sm[(t * 3 + part) * W + 4 * c4]) =
+            *reinterpret_cast<const f32x4 *>(qkv + ((long long)(b * T + t) * P + p) * C3 + part * C + hg * W + 4 * c4);
     }
-    for (int idx = tid; idx < T * n1; idx += 64) {
-        const int t = idx / n1, c4 = idx - t * n1;
-        *reinterpret_cast<f32x4 *>(&sG[t * C + 4 * c4]) = *reinterpret_cast<const f32x4 *>(dout + ((long long)(b * T + t) * P + p) * C + 4 * c4);
+    for (int idx = tid; idx < T * w4; idx += nthr) {
+        const int t = idx / w4, c4 = idx - t * w4;
+        *reinterpret_cast<f32x4 *>(&sG[t * W + 4 * c4]) = *reinterpret_cast<const f32x4 *>(dout + ((long long)(b * T + t) * P + p) * C + hg * W + 4 * c4);
     }
     __syncthreads();
-    const int head = tid % heads, t = tid / heads;
-    const int d = C / heads;
+    const int hl = tid % HG, t = tid / HG;
     const bool live = t < T;
     const int tc = live ? t : T - 1;
-    const float *q = sm + tc * C3 + head * d, *g = sG + tc * C + head * d;
-    float s[8], dp[8];
+    const float *q = sm + (tc * 3 + 0) * W + hl * d, *g = sG + tc * W + hl * d;
+    float s[TMAX], dp[TMAX];
 #pragma unroll
-    for (int ts = 0; ts < 8; ++ts) s[ts] = dp[ts] = 0.f;
+    for (int ts = 0; ts < TMAX; ++ts) s[ts] = dp[ts] = 0.f;
     for (int c = 0; c < d; c += 4) {
         const f32x4 q4 = *reinterpret_cast<const f32x4 *>(q + c), g4 = *reinterpret_cast<const f32x4 *>(g + c);
 #pragma unroll
-        for (int ts = 0; ts < 8; ++ts)
+        for (int ts = 0; ts < TMAX; ++ts)
             if (ts < T) {
-                const f32x4 k4 = *reinterpret_cast<const f32x4 *>(sm + ts * C3 + C + head * d + c);
-                const f32x4 v4 = *reinterpret_cast<const f32x4 *>(sm + ts * C3 + 2 * C + head * d + c);
+                const f32x4 k4 = *reinterpret_cast<const f32x4 *>(sm + (ts * 3 + 1) * W + hl * d + c);
+                const f32x4 v4 = *reinterpret_cast<const f32x4 *>(sm + (ts * 3 + 2) * W + hl * d + c);
                 s[ts] += (q4.x * k4.x + q4.y * k4.y) + (q4.z * k4.z + q4.w * k4.w);
                 dp[ts] += (g4.x * v4.x + g4.y * v4.y) + (g4.z * v4.z + g4.w * v4.w);
             }
     }
     float mx = -INFINITY;
 #pragma unroll
-    for (int ts = 0; ts < 8; ++ts)
+    for (int ts = 0; ts < TMAX; ++ts)
         if (ts < T) {
             s[ts] *= scale;
             mx = fmaxf(mx, s[ts]);
         }
     float sum = 0.f;
 #pragma unroll
-    for (int ts = 0; ts < 8; ++ts) {
+    for (int ts = 0; ts < TMAX; ++ts) {
         s[ts] = ts < T ? expf(s[ts] - mx) : 0.f;
         sum += s[ts];
     }
     const float inv = 1.0f / sum;
     float dot = 0.f;
 #pragma unroll
-    for (int ts = 0; ts < 8; ++ts) {
+    for (int ts = 0; ts < TMAX; ++ts) {
         s[ts] *= inv;  // P
         dot += s[ts] * dp[ts];
     }
 #pragma unroll
-    for (int ts = 0; ts < 8; ++ts) {
+    for (int ts = 0; ts < TMAX; ++ts) {
         dp[ts] = s[ts] * (dp[ts] - dot) * scale;  // dS * scale (zero for ts >= T)
         if (live) {  // threads with t >= T only keep the barrier company
-            sP[(head * T + t) * 8 + ts] = s[ts];
-            sS[(head * T + t) * 8 + ts] = dp[ts];
+            sP[(hl * T + t) * TMAX + ts] = s[ts];
+            sS[(hl * T + t) * TMAX + ts] = dp[ts];
         }
     }
-    float *orow = dqkv + ((long long)(b * T + tc) * P + p) * C3 + head * d;
+    float *orow = dqkv + ((long long)(b * T + tc) * P + p) * C3 + hg * W + hl * d;
     if (live)
         for (int c = 0; c < d; c += 4) {  // dQ[t] = sum_ts dS[t][ts] K[ts]
             f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ts = 0; ts < 8; ++ts)
-                if (ts < T) acc += dp[ts] * *reinterpret_cast<const f32x4 *>(sm + ts * C3 + C + head * d + c);
+            for (int ts = 0; ts < TMAX; ++ts)
+                if (ts < T) acc += dp[ts] * *reinterpret_cast<const f32x4 *>(sm + (ts * 3 + 1) * W + hl * d + c);
             *reinterpret_cast<f32x4 *>(orow + c) = acc;
         }
     __syncthreads();
     if (!live) return;
-    float ps[8], ds[8];  // column t of P and dS: over the queries
+    // column t of P and dS (over the queries) replaces the rows in the same registers
 #pragma unroll
-    for (int tq = 0; tq < 8; ++tq) {
-        ps[tq] = tq < T ? sP[(head * T + tq) * 8 + t] : 0.f;
-        ds[tq] = tq < T ? sS[(head * T + tq) * 8 + t] : 0.f;
+    for (int tq = 0; tq < TMAX; ++tq) {
+        s[tq] = tq < T ? sP[(hl * T + tq) * TMAX + t] : 0.f;
+        dp[tq] = tq < T ? sS[(hl * T + tq) * TMAX + t] : 0.f;
     }
     for (int c = 0; c < d; c += 4) {
         f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dv = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int tq = 0; tq < 8; ++tq)
+        for (int tq = 0; tq < TMAX; ++tq)
             if (tq < T) {
-                dk += ds[tq] * *reinterpret_cast<const f32x4 *>(sm + tq * C3 + head * d + c);
-                dv += ps[tq] * *reinterpret_cast<const f32x4 *>(sG + tq * C + head * d + c);
+                dk += dp[tq] * *reinterpret_cast<const f32x4 *>(sm + (tq * 3 + 0) * W + hl * d + c);
+                dv += s[tq] * *reinterpret_cast<const f32x4 *>(sG + tq * W + hl * d + c);
             }
         *reinterpret_cast<f32x4 *>(orow + C + c) = dk;
         *reinterpret_cast<f32x4 *>(orow + 2 * C + c) = dv;
@@ -856,14 +861,24 @@ int attn_temporal_bwd(const float *qkv, const float *dout, float *dqkv, int B, i
     EDV_CHECK(blocks < (1ll << 31), "grid");
     const float scale = 1.0f / sqrtf((float)(C / heads));
     dim3 grid((unsigned)blocks), block(64);
-    const size_t lds = ((size_t)T * 4 * C + (size_t)2 * heads * T * 8) * sizeof(float);
     static const bool per_thread = [] {
-        const char *e = getenv("EDV_TATTN_BWD_PER_THREAD");  // 1: the one-thread-per-(pixel, head) kernel also for T <= 8 (A/B runs)
+        const char *e = getenv("EDV_TATTN_BWD_PER_THREAD");  // 1: the one-thread-per-(pixel, head) kernel only (A/B runs)
         return e && atoi(e) != 0;
     }();
-    if (T <= 8 && heads == 8 && lds <= 64 * 1024 && (long long)B * P < (1ll << 31) && !per_thread)
-        hipLaunchKernelGGL(attn_temporal_bwd_pixel_kernel, dim3((unsigned)(B * P)), dim3(64), lds, st, qkv, dout, dqkv, T, P, C, heads, scale);
-    else if (T <= 8)
+    const int d = C / heads, TM = T <= 8 ? 8 : (T <= 16 ? 16 : 32);
+    auto lds_of = [&](int hgv) { return ((size_t)T * 4 * hgv * d + (size_t)2 * hgv * T * TM) * sizeof(float); };
+    int HG = heads;  // heads per workgroup: as many as fit 256 threads and 64 KB of LDS
+    while (HG > 1 && ((long long)T * HG > 256 || lds_of(HG) > 64 * 1024 || heads % HG != 0)) --HG;
+    const bool pixel_fits = d % 4 == 0 && (long long)T * HG <= 256 && lds_of(HG) <= 64 * 1024 && (long long)B * P * (heads / HG) < (1ll << 31);
+    if (pixel_fits && !per_thread) {
+        const dim3 g3((unsigned)((long long)B * P * (heads / HG))), b3((unsigned)(((T * HG + 63) / 64) * 64));
+        if (TM == 8)
+            hipLaunchKernelGGL(attn_temporal_bwd_pixel_kernel<8>, g3, b3, lds_of(HG), st, qkv, dout, dqkv, T, P, C, heads, HG, scale);
+        else if (TM == 16)
+            hipLaunchKernelGGL(attn_temporal_bwd_pixel_kernel<16>, g3, b3, lds_of(HG), st, qkv, dout, dqkv, T, P, C, heads, HG, scale);
+        else
+            hipLaunchKernelGGL(attn_temporal_bwd_pixel_kernel<32>, g3, b3, lds_of(HG), st, qkv, dout, dqkv, T, P, C, heads, HG, scale);
+    } else if (T <= 8)
         hipLaunchKernelGGL(attn_temporal_bwd_kernel<8>, grid, block, 0, st, qkv, dout, dqkv, B, T, P, C, heads, scale);
     else if (T <= 16)
         hipLaunchKernelGGL(attn_temporal_bwd_kernel<16>, grid, block, 0, st, qkv, dout, dqkv, B, T, P, C, heads, scale);

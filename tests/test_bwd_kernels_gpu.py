@@ -221,7 +221,7 @@ def test_groupnorm_bwd(lib, cuda, Fr, P, Cc, acc):
 
 
 @pytest.mark.parametrize("Bc,T,P,Cc", [(1, 8, 300, 192), (2, 3, 50, 64), (1, 16, 61, 384), (1, 32, 41, 32), (1, 1, 9, 64), (1, 8, 361, 384), (2, 5, 77, 64),
-                                       (1, 8, 1500, 64)])
+                                       (1, 8, 1500, 64), (1, 16, 361, 768), (1, 16, 300, 128), (1, 32, 60, 1024), (2, 12, 50, 512), (1, 32, 200, 256)])
 def test_attn_temporal_bwd(lib, cuda, Bc, T, P, Cc):
     heads, d = 8, Cc // 8
     rows = Bc * T * P

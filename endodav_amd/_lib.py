@@ -11,7 +11,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EDV_LIB_PATH") or os.path.join(_HERE, "lib", "libendodav_hip.so")  # override: experiments only
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 LORA_TYPES = {"none": 0, "lora": 1, "dvlora": 2, "ssb": 3, "dash": 4}
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_SIGMOID_NEG = 0, 1, 2, 3, 4
@@ -42,6 +42,8 @@ class EdvConfig(C.Structure):
         ("dash_active", C.c_int32),
         ("use_clstoken", C.c_int32),
         ("residual_mask", C.c_uint32),
+        ("use_bn", C.c_int32),
+        ("pe_rope", C.c_int32),
     ]
 
 
@@ -101,6 +103,7 @@ SIGNATURES = {
     "edv_attn_temporal": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
     "edv_groupnorm": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _f32, C.c_void_p]),
     "edv_geglu": (C.c_int, [_fp, _fp, _i64, _i32, C.c_void_p]),
+    "edv_rope_qk": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
     "edv_bilinear": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
     "edv_dot_channels": (C.c_int, [_fp, _fp, _fp, _fp, _i64, _i32, _i32, C.c_void_p]),
     "edv_patchify": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),

@@ -141,6 +141,10 @@ int edv_attn_temporal(const float *qkv_dev, float *out_dev, int32_t B, int32_t T
     return attn_temporal(qkv_dev, out_dev, B, T, P, C, heads, (hipStream_t)stream);
 }
 
+int edv_rope_qk(float *qkv_dev, const float *table_dev, int32_t B, int32_t T, int32_t P, int32_t C, int32_t transpose, void *stream) {
+    return rope_qk(qkv_dev, table_dev, B, T, P, C, transpose != 0, (hipStream_t)stream);
+}
+
 int edv_groupnorm(const float *x_dev, const float *w_dev, const float *b_dev, float *y_dev, float *stats_dev, int32_t F, int32_t P, int32_t C,
                   int32_t groups, float eps, void *stream) {
     return groupnorm(x_dev, w_dev, b_dev, y_dev, stats_dev, F, P, C, groups, eps, (hipStream_t)stream);

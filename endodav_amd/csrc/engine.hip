@@ -154,6 +154,11 @@ struct Run {
     }
     int wsbuf(const std::string &name, size_t n, float **out) { return alloc_buf(c, c->ws, name, n, st, out); }
     int pk(const std::string &name, size_t n, float **out) { return alloc_buf(c, c->packed, name, n, st, out); }
+    // bias of a ResidualConvUnit convolution: with use_bn the one edv_prepare folded the BatchNorm into
+    int rcu_bias(const std::string &conv, const float **out) {
+        if (cfg.use_bn) return packedw(conv + ".bias", out);
+        return param(conv + ".bias", out);
+    }
 
     // ---- op wrappers ----------------------------------------------------------------------
     bool stagger_record = false;  // encoder_range records ev_x[5] after block 0's qkv GEMM (start signal for the next frame group)
@@ -258,6 +263,21 @@ struct Run {
         EDV_TRY(pk(p + ".weight", (size_t)q.numel(), &out));
         return pack_conv3x3(w, out, (int)q.shape[0], (int)q.shape[1], st);
     }
+    // eval-mode BatchNorm after convolution `conv` (util/blocks.py:80-86) folded into its packed weight and a packed bias
+    int fold_bn_into(const std::string &conv, const std::string &bn) {
+        const float *b, *g, *beta, *mean, *var;
+        EDV_TRY(param(conv + ".bias", &b));
+        EDV_TRY(param(bn + ".weight", &g));
+        EDV_TRY(param(bn + ".bias", &beta));
+        EDV_TRY(param(bn + ".running_mean", &mean));
+        EDV_TRY(param(bn + ".running_var", &var));
+        const Param &q = c->params[conv + ".weight"];
+        const int nout = (int)q.shape[0], K = (int)(q.numel() / q.shape[0]);
+        float *w, *bo;
+        EDV_TRY(pk(conv + ".weight", (size_t)q.numel(), &w));
+        EDV_TRY(pk(conv + ".bias", (size_t)nout, &bo));
+        return fold_bn(w, b, g, beta, mean, var, 1e-5f, bo, nout, K, st);
+    }
 
     int prepare() {
         c->launches = 0;
@@ -290,6 +310,10 @@ struct Run {
                 const std::string p = "head.scratch.refinenet" + std::to_string(j) + ".resConfUnit" + std::to_string(u);
                 EDV_TRY(pack_c3(p + ".conv1"));
                 EDV_TRY(pack_c3(p + ".conv2"));
+                if (cfg.use_bn) {
+                    EDV_TRY(fold_bn_into(p + ".conv1", p + ".bn1"));
+                    EDV_TRY(fold_bn_into(p + ".conv2", p + ".bn2"));
+                }
             }
         if (cfg.conv_head) {
             for (int k = 1; k <= 4; ++k) {
@@ -395,13 +419,18 @@ struct Run {
         EDV_TRY(linear(gn, M, C, w, C, b, hs[0]));
         for (int a = 0; a < 2; ++a) {
             const std::string ab = tb + ".attention_blocks." + std::to_string(a);
-            const float *pe;
-            EDV_TRY(param(ab + ".pos_encoder.pe", &pe));
+            const float *pe = nullptr, *rope = nullptr;  // "ape": sinusoid added by the LayerNorm kernel; "rope": q|k rotated after the projection
+            if (cfg.pe_rope) EDV_TRY(param(ab + ".freqs_cis", &rope, 3));
+            else EDV_TRY(param(ab + ".pos_encoder.pe", &pe));
             EDV_TRY(wsbuf(c->train ? tg + "qkv" + std::to_string(a) : sc_ + "qkv", (size_t)M * 3 * C, &qkv3));
             EDV_TRY(ln(hs[a], identity_map(), tb + ".norms." + std::to_string(a), hn, M, C, 1e-5f, pe, P, T));
             const float *wqkv;
             EDV_TRY(packedw(ab + ".qkv", &wqkv));
             EDV_TRY(linear(hn, M, C, wqkv, 3 * C, nullptr, qkv3));
+            if (rope) {
+                EDV_TRY(rope_qk(qkv3, rope, B, T, P, C, false, st));
+                c->launches++;
+            }
             {
                 Bracket b_(c, KC_ATTN_TEMPORAL, st);
                 EDV_TRY(attn_temporal(qkv3, att, B, T, P, C, 8, st));
@@ -455,9 +484,9 @@ struct Run {
         if (skip) {
             EDV_TRY(wsbuf(tg + "s", n, &s));
             EDV_TRY(packedw(p + ".resConfUnit1.conv1.weight", &w1));
-            EDV_TRY(param(p + ".resConfUnit1.conv1.bias", &b1));
+            EDV_TRY(rcu_bias(p + ".resConfUnit1.conv1", &b1));
             EDV_TRY(packedw(p + ".resConfUnit1.conv2.weight", &w2));
-            EDV_TRY(param(p + ".resConfUnit1.conv2.bias", &b2));
+            EDV_TRY(rcu_bias(p + ".resConfUnit1.conv2", &b2));
             EDV_TRY(conv3(skip, h, w, Fe, w1, b1, Fe, 1, t1a, true));
             // s = x + rcu1(skip) = x + skip + conv2(relu(t1)): both adds ride the conv2 epilogue
             // (skip_add at util/blocks.py:90 and :146)
@@ -465,9 +494,9 @@ struct Run {
             cur = s;
         }
         EDV_TRY(packedw(p + ".resConfUnit2.conv1.weight", &w1));
-        EDV_TRY(param(p + ".resConfUnit2.conv1.bias", &b1));
+        EDV_TRY(rcu_bias(p + ".resConfUnit2.conv1", &b1));
         EDV_TRY(packedw(p + ".resConfUnit2.conv2.weight", &w2));
-        EDV_TRY(param(p + ".resConfUnit2.conv2.bias", &b2));
+        EDV_TRY(rcu_bias(p + ".resConfUnit2.conv2", &b2));
         EDV_TRY(conv3(cur, h, w, Fe, w1, b1, Fe, 1, t1b, true));
         EDV_TRY(conv3(t1b, h, w, Fe, w2, b2, Fe, 1, t2, true, ACT_NONE, cur, nullptr));
         const float *wo, *bo;
@@ -487,9 +516,9 @@ struct Run {
         EDV_TRY(wsbuf("fus.t" + std::to_string(j), (size_t)F * h * w * Fe, &t));
         const float *w1, *b1, *w2, *b2;
         EDV_TRY(packedw(p + ".resConfUnit1.conv1.weight", &w1));
-        EDV_TRY(param(p + ".resConfUnit1.conv1.bias", &b1));
+        EDV_TRY(rcu_bias(p + ".resConfUnit1.conv1", &b1));
         EDV_TRY(packedw(p + ".resConfUnit1.conv2.weight", &w2));
-        EDV_TRY(param(p + ".resConfUnit1.conv2.bias", &b2));
+        EDV_TRY(rcu_bias(p + ".resConfUnit1.conv2", &b2));
         EDV_TRY(conv3(skip, h, w, Fe, w1, b1, Fe, 1, t, true));
         return conv3(t, h, w, Fe, w2, b2, Fe, 1, u, true, ACT_NONE, skip, nullptr);
     }
@@ -502,9 +531,9 @@ struct Run {
         EDV_TRY(wsbuf("fu.t2", n, &t2));
         const float *w1, *b1, *w2, *b2, *wo, *bo;
         EDV_TRY(packedw(p + ".resConfUnit2.conv1.weight", &w1));
-        EDV_TRY(param(p + ".resConfUnit2.conv1.bias", &b1));
+        EDV_TRY(rcu_bias(p + ".resConfUnit2.conv1", &b1));
         EDV_TRY(packedw(p + ".resConfUnit2.conv2.weight", &w2));
-        EDV_TRY(param(p + ".resConfUnit2.conv2.bias", &b2));
+        EDV_TRY(rcu_bias(p + ".resConfUnit2.conv2", &b2));
         EDV_TRY(conv3(sx, h, w, Fe, w1, b1, Fe, 1, t1, true));
         EDV_TRY(conv3(t1, h, w, Fe, w2, b2, Fe, 1, t2, true, ACT_NONE, sx, nullptr));
         EDV_TRY(param(p + ".out_conv.weight", &wo));
@@ -1029,6 +1058,7 @@ struct Run {
         return pack_conv3x3_bwd(w, out, (int)q.shape[0], (int)q.shape[1], st);
     }
     int prepare_train() {
+        EDV_CHECK(!cfg.use_bn, "the fine-tune step with use_bn=True is not built (train-mode BatchNorm uses batch statistics)");
         EDV_CHECK(c->prepared, "edv_prepare has not run");
         EDV_CHECK(!cfg.conv_head && !cfg.use_clstoken && !cfg.residual_mask && !cfg.out_sigmoid,
                   "training supports the VDA head without use_clstoken / residual blocks / out_sigmoid");
@@ -1133,7 +1163,12 @@ struct Run {
         for (int a = 1; a >= 0; --a) {
             const std::string ab = tb + ".attention_blocks." + std::to_string(a);
             EDV_TRY(dgemm(dh, M, C, ab + ".to_out.0", C, t1));             // h(a+1) = h(a) + to_out(att)
-            EDV_TRY(attn_temporal_bwd(qkvs[a], t1, t3, B, T, P, C, 8, st));
+            EDV_TRY(attn_temporal_bwd(qkvs[a], t1, t3, B, T, P, C, 8, st));  // qkvs[a] holds the rotated q|k under pe="rope"
+            if (cfg.pe_rope) {
+                const float *rope;
+                EDV_TRY(param(ab + ".freqs_cis", &rope, 3));
+                EDV_TRY(rope_qk(t3, rope, B, T, P, C, true, st));
+            }
             EDV_TRY(dgemm(t3, M, 3 * C, ab + ".qkv", C, t1));
             EDV_TRY(param(tb + ".norms." + std::to_string(a) + ".weight", &w));
             EDV_TRY(layernorm_bwd(hsv[a], identity_map(), w, t1, identity_map(), dh, identity_map(), M, C, 1e-5f, true, st));

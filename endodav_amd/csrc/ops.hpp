@@ -78,6 +78,8 @@ int attn_spatial_bwd(const float *qkv, const float *out, const float *dout, cons
                      size_t ws_floats, hipStream_t st);
 int attn_temporal(const float *qkv, float *out, int B, int T, int P, int C, int heads, hipStream_t st);
 int geglu(const float *x, float *y, long long M, int inner, hipStream_t st);
+// pe="rope": q|k of qkv [B*T*P, 3C] rotated in place by the tabulated cos|sin [>=T, C/2, 2]; transpose = the rotation's adjoint
+int rope_qk(float *qkv, const float *table, int B, int T, int P, int C, bool transpose, hipStream_t st);
 
 // ------------------------------------------------------------------------------------------
 // norms (norms.hip)
@@ -111,6 +113,9 @@ int copy_f32(const float *src, float *dst, long long n, hipStream_t st);
 int fold_lora(const float *W, const float *A, const float *B, const float *U, const float *V, float scale, float *out, int nout, int nin,
               int r, hipStream_t st);
 int fold_ssb(const float *W, const float *a, const float *b, float *out, int nout, int nin, hipStream_t st);
+// eval-mode BatchNorm after a convolution: rows of the packed weight [nout, K] scaled in place, bout = folded bias
+int fold_bn(float *w, const float *b, const float *gamma, const float *beta, const float *mean, const float *var, float eps, float *bout, int nout, int K,
+            hipStream_t st);
 // W_eff += Utop diag(idx) Vtop  (DashLinear after warm-up)
 int fold_dash(const float *Utop, const float *idx, const float *Vtop, float *inout, int nout, int nin, int r, hipStream_t st);
 

@@ -75,6 +75,18 @@ __global__ void fold_dash_kernel(const float *__restrict__ Ut, const float *__re
 
 inline unsigned blocks_for(long long n) { return (unsigned)((n + 255) / 256); }
 
+// Eval-mode BatchNorm2d folded into the preceding convolution (use_bn=True: util/blocks.py:60-62,80-86):
+// bn(conv(x)) = s * (W x + b - mean) + beta with s = gamma / sqrt(var + eps)  ->  W' = s ∘ W (row n of the packed weight), b' = s (b - mean) + beta.
+__global__ void fold_bn_kernel(float *__restrict__ w, const float *__restrict__ b, const float *__restrict__ gamma, const float *__restrict__ beta,
+                               const float *__restrict__ mean, const float *__restrict__ var, float eps, float *__restrict__ bout, int nout, int K) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long long)nout * K) return;
+    const int n = (int)(i / K);
+    const float s = gamma[n] / sqrtf(var[n] + eps);
+    w[i] *= s;
+    if (i - (long long)n * K == 0) bout[n] = (b[n] - mean[n]) * s + beta[n];
+}
+
 }  // namespace
 
 int pack_conv3x3(const float *w, float *out, int Cout, int Cin, hipStream_t st) {
@@ -117,6 +129,14 @@ int fold_ssb(const float *W, const float *a, const float *b, float *out, int nou
 int fold_dash(const float *Utop, const float *idx, const float *Vtop, float *inout, int nout, int nin, int r, hipStream_t st) {
     EDV_CHECK(Utop && idx && Vtop && inout && nout > 0 && nin > 0 && r > 0, "bad operand");
     hipLaunchKernelGGL(fold_dash_kernel, dim3(blocks_for((long long)nout * nin)), dim3(256), 0, st, Utop, idx, Vtop, inout, nout, nin, r);
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
+int fold_bn(float *w, const float *b, const float *gamma, const float *beta, const float *mean, const float *var, float eps, float *bout, int nout, int K,
+            hipStream_t st) {
+    EDV_CHECK(w && b && gamma && beta && mean && var && bout && nout > 0 && K > 0, "bad operand");
+    hipLaunchKernelGGL(fold_bn_kernel, dim3(blocks_for((long long)nout * K)), dim3(256), 0, st, w, b, gamma, beta, mean, var, eps, bout, nout, K);
     EDV_LAUNCH_OK();
     return 0;
 }

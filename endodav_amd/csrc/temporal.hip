@@ -215,6 +215,27 @@ __global__ __launch_bounds__(256) void geglu_kernel(const float *__restrict__ x,
     }
 }
 
+
+// Rotary position embedding of the temporal attention (pe="rope": motion_module.py:221-225,252-255; attention.py:402-429).
+// q and k of row m (frame t = (m / P) % T) are rotated in place, channel pairs (2i, 2i+1) by the angle t * freq_i whose
+// cos|sin the host tabulated with the reference's own expression (table [>=T, C/2, 2]).  The rotation spans the full channel
+// width C (before the head split).  sign = -1 applies the transpose = the input gradient of the rotation.
+__global__ __launch_bounds__(256) void rope_qk_kernel(float *__restrict__ qkv, const float *__restrict__ table, long long n_pairs, int T, int P, int C,
+                                                      float sign) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n_pairs) return;
+    const int half = C >> 1;
+    const long long m = i / half;
+    const int j = (int)(i - m * half);
+    const int t = (int)((m / P) % T);
+    const float2 cs = *reinterpret_cast<const float2 *>(table + ((size_t)t * half + j) * 2);
+    const float c = cs.x, sn = sign * cs.y;
+    float2 *q = reinterpret_cast<float2 *>(qkv + m * 3 * C + 2 * j), *k = reinterpret_cast<float2 *>(qkv + m * 3 * C + C + 2 * j);
+    const float2 a = *q, b = *k;
+    *q = make_float2(a.x * c - a.y * sn, a.x * sn + a.y * c);
+    *k = make_float2(b.x * c - b.y * sn, b.x * sn + b.y * c);
+}
+
 }  // namespace
 
 int attn_temporal(const float *qkv, float *out, int B, int T, int P, int C, int heads, hipStream_t st) {
@@ -269,6 +290,15 @@ int geglu(const float *x, float *y, long long M, int inner, hipStream_t st) {
     const long long total4 = M * (inner / 4);
     const int blocks = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
     hipLaunchKernelGGL(geglu_kernel, dim3(blocks), dim3(256), 0, st, x, y, total4, inner / 4);
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
+int rope_qk(float *qkv, const float *table, int B, int T, int P, int C, bool transpose, hipStream_t st) {
+    EDV_CHECK(qkv && table, "null operand");
+    EDV_CHECK(B > 0 && T > 0 && P > 0 && C > 0 && C % 2 == 0, "bad shape");
+    const long long n = (long long)B * T * P * (C / 2);
+    hipLaunchKernelGGL(rope_qk_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, qkv, table, n, T, P, C, transpose ? -1.f : 1.f);
     EDV_LAUNCH_OK();
     return 0;
 }

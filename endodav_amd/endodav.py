@@ -215,14 +215,27 @@ class _PosEnc(_Holder):  # motion_module.py:180-198
         self.register_buffer("pe", pe)
 
 
+def _rope_table(dim, max_len, theta=10000.0):
+    """(cos, sin) of attention.py:402-408 (precompute_freqs_cis) as a real tensor [max_len, dim/2, 2]."""
+    freqs = 1.0 / (theta ** (torch.arange(0, dim, 2)[: (dim // 2)].float() / dim))
+    ang = torch.outer(torch.arange(max_len, dtype=torch.float32), freqs)
+    return torch.view_as_real(torch.polar(torch.ones_like(ang), ang)).contiguous()
+
+
 class _TemporalAttention(_Holder):  # motion_module.py:200-228 + attention.py:44-91
-    def __init__(self, dim, max_len):
+    def __init__(self, dim, max_len, pe="ape"):
         super().__init__()
         self.to_q = nn.Linear(dim, dim, bias=False)
         self.to_k = nn.Linear(dim, dim, bias=False)
         self.to_v = nn.Linear(dim, dim, bias=False)
         self.to_out = nn.ModuleList([nn.Linear(dim, dim), nn.Dropout(0.0)])
-        self.pos_encoder = _PosEnc(dim, max_len)
+        if pe == "ape":  # motion_module.py:214-219
+            self.pos_encoder = _PosEnc(dim, max_len)
+        elif pe == "rope":  # :221-225 — a plain attribute in the reference: not part of the state_dict
+            self.pos_encoder = None
+            self.register_buffer("freqs_cis", _rope_table(dim, max_len), persistent=False)
+        else:
+            raise NotImplementedError  # motion_module.py:227-228
 
 
 class _GEGLU(_Holder):  # attention.py:363-384
@@ -238,44 +251,47 @@ class _FeedForward(_Holder):  # attention.py:296-338
 
 
 class _TemporalBlock(_Holder):  # motion_module.py:129-177
-    def __init__(self, dim, max_len):
+    def __init__(self, dim, max_len, pe="ape"):
         super().__init__()
-        self.attention_blocks = nn.ModuleList([_TemporalAttention(dim, max_len) for _ in range(2)])
+        self.attention_blocks = nn.ModuleList([_TemporalAttention(dim, max_len, pe) for _ in range(2)])
         self.norms = nn.ModuleList([nn.LayerNorm(dim) for _ in range(2)])
         self.ff = _FeedForward(dim)
         self.ff_norm = nn.LayerNorm(dim)
 
 
 class _TemporalTransformer(_Holder):  # motion_module.py:68-126
-    def __init__(self, channels, max_len):
+    def __init__(self, channels, max_len, pe="ape"):
         super().__init__()
         self.norm = nn.GroupNorm(num_groups=32, num_channels=channels, eps=1e-6, affine=True)
         self.proj_in = nn.Linear(channels, channels)
-        self.transformer_blocks = nn.ModuleList([_TemporalBlock(channels, max_len)])
+        self.transformer_blocks = nn.ModuleList([_TemporalBlock(channels, max_len, pe)])
         self.proj_out = nn.Linear(channels, channels)
 
 
 class TemporalModule(_Holder):  # motion_module.py:32-65, zero_initialize=True
-    def __init__(self, in_channels, max_len):
+    def __init__(self, in_channels, max_len, pe="ape"):
         super().__init__()
-        self.temporal_transformer = _TemporalTransformer(in_channels, max_len)
+        self.temporal_transformer = _TemporalTransformer(in_channels, max_len, pe)
         for p in self.temporal_transformer.proj_out.parameters():
             p.detach().zero_()
 
 
 class _RCU(_Holder):  # util/blocks.py:37-66
-    def __init__(self, f):
+    def __init__(self, f, bn=False):
         super().__init__()
         self.conv1 = nn.Conv2d(f, f, 3, 1, 1, bias=True)
         self.conv2 = nn.Conv2d(f, f, 3, 1, 1, bias=True)
+        if bn:  # :60-62
+            self.bn1 = nn.BatchNorm2d(f)
+            self.bn2 = nn.BatchNorm2d(f)
 
 
 class _Fusion(_Holder):  # util/blocks.py:94-133
-    def __init__(self, f):
+    def __init__(self, f, bn=False):
         super().__init__()
         self.out_conv = nn.Conv2d(f, f, 1, 1, 0, bias=True)
-        self.resConfUnit1 = _RCU(f)
-        self.resConfUnit2 = _RCU(f)
+        self.resConfUnit1 = _RCU(f, bn)
+        self.resConfUnit2 = _RCU(f, bn)
 
 
 class _Interp(nn.Module):  # endodav/layers.py:194-204; no parameters, keeps Sequential indices 0,2,4
@@ -291,7 +307,7 @@ class HeadDepth(_Holder):  # endodav/layers.py:206-221
 class _Head(_Holder):
     """Parameter tree of DPTHeadPyramid (dpt.py:47-124, dpt_temporal.py:22-51, dpt_pyramid.py:22-49)."""
 
-    def __init__(self, in_channels, features, out_channels, num_frames, disable_conv_head, use_clstoken=False):
+    def __init__(self, in_channels, features, out_channels, num_frames, disable_conv_head, use_clstoken=False, use_bn=False, pe="ape"):
         super().__init__()
         oc = list(out_channels)
         self.use_clstoken = use_clstoken
@@ -309,15 +325,15 @@ class _Head(_Holder):
             setattr(s, f"layer{j + 1}_rn", nn.Conv2d(oc[j], features, 3, 1, 1, bias=False))
         s.stem_transpose = None
         for j in (1, 2, 3, 4):
-            setattr(s, f"refinenet{j}", _Fusion(features))
+            setattr(s, f"refinenet{j}", _Fusion(features, use_bn))
         if disable_conv_head:
             s.output_conv1 = nn.Conv2d(features, features // 2, 3, 1, 1)
             s.output_conv2 = nn.Sequential(nn.Conv2d(features // 2, 32, 3, 1, 1), nn.ReLU(True), nn.Conv2d(32, 1, 1, 1, 0), nn.ReLU(True), nn.Identity())
         self.scratch = s
         assert num_frames > 0  # dpt_temporal.py:34
         self.motion_modules = nn.ModuleList([
-            TemporalModule(oc[2], num_frames), TemporalModule(oc[3], num_frames),
-            TemporalModule(features, num_frames), TemporalModule(features, num_frames),
+            TemporalModule(oc[2], num_frames, pe), TemporalModule(oc[3], num_frames, pe),
+            TemporalModule(features, num_frames, pe), TemporalModule(features, num_frames, pe),
         ])
         self.disable_conv_head = disable_conv_head
         if not disable_conv_head:
@@ -399,10 +415,6 @@ class endodav(nn.Module):
     ):
         super().__init__()
         dim, depth, heads, img_size, taps = ENCODERS[encoder]  # KeyError for an unknown encoder, like endodav.py:92
-        if use_bn:
-            raise NotImplementedError("use_bn=True (BatchNorm in the fusion blocks) is not built; no reference caller sets it")
-        if pe != "ape":
-            raise NotImplementedError("only pe='ape' (the reference default) is built")
         residual_block_indexes = [int(i) for i in residual_block_indexes]
         self.encoder = encoder
         self.intermediate_layer_idx = {encoder: list(taps)}
@@ -415,11 +427,12 @@ class endodav(nn.Module):
         self.temporal_lora, self.disable_conv_head = temporal_lora, disable_conv_head
         self.features, self.out_channels = features, list(out_channels)
         self.use_clstoken = bool(use_clstoken)
+        self.use_bn, self.pe = bool(use_bn), pe
         self.residual_block_indexes = [i for i in residual_block_indexes if 0 <= i < depth]
         self._dash_calls = 0  # DashLinear.FLAG of the reference, one shared count (every Dash layer sees every forward)
 
         self.pretrained = _Backbone(dim, depth, heads, img_size, self.residual_block_indexes)
-        self.head = _Head(dim, features, out_channels, num_frames, disable_conv_head, self.use_clstoken)
+        self.head = _Head(dim, features, out_channels, num_frames, disable_conv_head, self.use_clstoken, self.use_bn, pe)
 
         if lora_type != "none":  # endodav.py:102-137
             for blk in self.pretrained.blocks:
@@ -465,6 +478,7 @@ class endodav(nn.Module):
         cfg.temporal_lora = int(bool(self.temporal_lora))
         cfg.dash_active = int(self.lora_type == "dash" and self._dash_calls > DashLinear.WARMUP)
         cfg.use_clstoken = int(self.use_clstoken)
+        cfg.use_bn, cfg.pe_rope = int(self.use_bn), int(self.pe == "rope")
         mask = 0
         for i in self.residual_block_indexes:
             mask |= 1 << i
@@ -484,6 +498,8 @@ class endodav(nn.Module):
         self._last = nat
         # (re)bind + repack whenever a tensor moved or was written (optimizer step, load_state_dict)
         sd = self.state_dict(keep_vars=True)
+        if self.pe == "rope":  # the rotary tables are not state (motion_module.py:221-225) but the engine reads them like weights
+            sd.update({k: v for k, v in self.named_buffers() if k.endswith(".freqs_cis")})
         sig = tuple((k, v.data_ptr(), v._version) for k, v in sd.items())
         if sig != nat.sig:
             for k, v in sd.items():
@@ -544,6 +560,9 @@ class endodav(nn.Module):
             raise ValueError(f"expected a clip [B, T, 3, H, W], got {tuple(x.shape)}")
         if not x.is_cuda:
             raise RuntimeError("endodav_amd runs on MI355X only: the clip must be a CUDA/ROCm tensor (there is no CPU fallback)")
+        if self.use_bn and self.training:
+            raise NotImplementedError("use_bn=True is built for eval() only: train-mode BatchNorm (batch statistics, running-average updates, "
+                                      "util/blocks.py:80-86) is not; no reference script sets use_bn")
         train_names: List[str] = []
         if torch.is_grad_enabled():
             if x.requires_grad:

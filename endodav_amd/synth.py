@@ -68,6 +68,8 @@ def param_range(name: str, shape: Tuple[int, ...]) -> Tuple[float, float] | None
     """(lo, hi) of the uniform law for state-dict entry ``name``; None = keep as built."""
     if name.endswith("pos_encoder.pe"):
         return None  # deterministic sinusoid buffer (motion_module.py:180-194)
+    if name.endswith(".running_var") or re.search(r"\.bn\d\.weight$", name):  # BatchNorm (use_bn=True): positive scales
+        return (0.5, 1.5)
     if name.endswith(".gamma"):  # LayerScale: far from the 1e-5 identity trap
         return (0.2, 1.0)
     if _NORM_W.search(name):

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EDV_ABI_VERSION 3
+#define EDV_ABI_VERSION 4
 
 enum edv_lora_type { EDV_LORA_NONE = 0, EDV_LORA_LORA = 1, EDV_LORA_DVLORA = 2, EDV_LORA_SSB = 3, EDV_LORA_DASH = 4 };
 
@@ -60,6 +60,9 @@ typedef struct edv_config {
     int32_t use_clstoken;       /* DPT readout projections, dpt_pyramid.py:54-57 */
     uint32_t residual_mask;     /* bit i set: encoder block i carries a ResBottleneckBlock (block.py:146-150);
                                  * the reference hard-wires its grid to 16x20 patches = image_shape (224, 280) */
+    int32_t use_bn;             /* eval-mode BatchNorm2d in the ResidualConvUnits (util/blocks.py:60-62,80-86), folded into the convolutions */
+    int32_t pe_rope;            /* pe="rope" (motion_module.py:221-225,252-255): rotary q/k instead of the additive sinusoid;
+                                 * needs a bound "<attention block>.freqs_cis" table [num_frames, C/2, 2] (cos, sin) per attention block */
 } edv_config;
 
 typedef struct edv_ctx edv_ctx;
@@ -169,6 +172,11 @@ int edv_attn_spatial_bwd(const float *qkv_dev, const float *out_dev, const float
 /* Temporal attention core, motion_module.py:230-297 + attention.py:182-211: qkv [B*T*P, 3C]
  * (q|k|v per row, 8 heads), softmax over the T frames of each pixel -> out [B*T*P, C]. */
 int edv_attn_temporal(const float *qkv_dev, float *out_dev, int32_t B, int32_t T, int32_t P, int32_t C, int32_t heads, void *stream);
+
+/* Rotary embedding of the temporal attention, attention.py:419-429: q|k of qkv [B*T*P, 3C] rotated in place, channel pairs
+ * (2i, 2i+1) of a row of frame t by the angle whose (cos, sin) is table[t, i, :] (table [>=T, C/2, 2], attention.py:402-408).
+ * transpose != 0 applies the adjoint (the gradient of the rotation with respect to its input). */
+int edv_rope_qk(float *qkv_dev, const float *table_dev, int32_t B, int32_t T, int32_t P, int32_t C, int32_t transpose, void *stream);
 
 /* GroupNorm(32 groups) on channels-last x [F,P,C] (motion_module.py:84,110). */
 int edv_groupnorm(const float *x_dev, const float *w_dev, const float *b_dev, float *y_dev, float *stats_dev /* [F*32*2] scratch */,

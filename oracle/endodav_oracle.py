@@ -54,6 +54,8 @@ class OracleConfig:
     residual_block_indexes: Sequence[int] = field(default_factory=tuple)
     temporal_heads: int = 8  # dpt_temporal.py:35
     dash_active: bool = False  # DashLinear past its 100-call warm-up (mylora/layers.py:572-583)
+    use_bn: bool = False  # eval-mode BatchNorm2d after both convs of every ResidualConvUnit (util/blocks.py:60-62,80-86)
+    pe: str = "ape"  # "ape": sinusoid added to the attention input; "rope": rotary q/k (motion_module.py:214-225,252-255)
     # test-only override so tiny encoders can be exercised: (embed_dim, depth, heads, taps)
     encoder_dims: Optional[Tuple[int, int, int, Tuple[int, ...]]] = None
 
@@ -206,8 +208,21 @@ def encoder_taps(sd: State, x: Tensor, cfg: OracleConfig, stages: Optional[dict]
 # ---------------------------------------------------------------------------
 # Motion module — models/endodav/motion_module/{motion_module,attention}.py
 # ---------------------------------------------------------------------------
-def temporal_attention(sd: State, p: str, xn: Tensor, T: int, heads: int) -> Tensor:
-    """motion_module.py:230-297 (ape branch) + attention.py:182-211.
+def rope_table(C: int, T: int, theta: float = 10000.0) -> Tuple[Tensor, Tensor]:
+    """cos, sin [T, C/2] of attention.py:402-408 (precompute_freqs_cis over the full channel width, before the head split)."""
+    freqs = 1.0 / (theta ** (torch.arange(0, C, 2)[: C // 2].float() / C))
+    ang = torch.outer(torch.arange(T, dtype=torch.float32), freqs)
+    return torch.cos(ang), torch.sin(ang)
+
+
+def rope_rotate(t: Tensor, cos: Tensor, sin: Tensor) -> Tensor:
+    """attention.py:419-429: channel pairs (2i, 2i+1) of row f rotated by f·freq_i.  ``t``: [N, T, C]."""
+    a, b = t[..., 0::2], t[..., 1::2]
+    return torch.stack((a * cos - b * sin, a * sin + b * cos), dim=-1).flatten(-2)
+
+
+def temporal_attention(sd: State, p: str, xn: Tensor, T: int, heads: int, pe: str = "ape") -> Tensor:
+    """motion_module.py:230-297 + attention.py:182-211.
 
     ``xn``: [(b·T), P, C] already layer-normed.  Returns the attention block output
     (to_out applied), same shape; the caller adds the residual.
@@ -215,10 +230,14 @@ def temporal_attention(sd: State, p: str, xn: Tensor, T: int, heads: int) -> Ten
     BT, P, C = xn.shape
     Bc = BT // T
     h = xn.reshape(Bc, T, P, C).permute(0, 2, 1, 3).reshape(Bc * P, T, C)  # "(b f) d c -> (b d) f c"
-    h = h + sd[p + ".pos_encoder.pe"][:, :T]  # PE enters q, k *and* v (motion_module.py:234-250)
+    if pe == "ape":
+        h = h + sd[p + ".pos_encoder.pe"][:, :T]  # PE enters q, k *and* v (motion_module.py:234-250)
     q = F.linear(h, sd[p + ".to_q.weight"])
     k = F.linear(h, sd[p + ".to_k.weight"])
     v = F.linear(h, sd[p + ".to_v.weight"])
+    if pe == "rope":  # motion_module.py:252-255
+        cos, sin = rope_table(C, T)
+        q, k = rope_rotate(q, cos, sin), rope_rotate(k, cos, sin)
     d = C // heads
 
     def split(t):
@@ -244,7 +263,7 @@ def motion_module(sd: State, m: int, x: Tensor, T: int, cfg: OracleConfig) -> Te
     b = p + ".transformer_blocks.0"
     for a in range(2):  # num_attention_blocks = 2 (dpt_temporal.py:37)
         n = F.layer_norm(t, (C,), sd[f"{b}.norms.{a}.weight"], sd[f"{b}.norms.{a}.bias"], 1e-5)
-        t = temporal_attention(sd, f"{b}.attention_blocks.{a}", n, T, cfg.temporal_heads) + t
+        t = temporal_attention(sd, f"{b}.attention_blocks.{a}", n, T, cfg.temporal_heads, cfg.pe) + t
     n = F.layer_norm(t, (C,), sd[b + ".ff_norm.weight"], sd[b + ".ff_norm.bias"], 1e-5)
     val, gate = F.linear(n, sd[b + ".ff.net.0.proj.weight"], sd[b + ".ff.net.0.proj.bias"]).chunk(2, dim=-1)
     ff = lora_linear(sd, b + ".ff.net.2", val * F.gelu(gate), cfg)  # GEGLU, attention.py:363-384
@@ -260,18 +279,23 @@ def _up(x: Tensor, size=None, scale=None) -> Tensor:
     return F.interpolate(x, size=size, scale_factor=scale, mode="bilinear", align_corners=True)
 
 
-def residual_conv_unit(sd: State, p: str, x: Tensor) -> Tensor:
-    """util/blocks.py:68-91 (bn=False): x + conv2(relu(conv1(relu(x))))."""
-    y = F.conv2d(F.relu(x), sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], padding=1)
-    y = F.conv2d(F.relu(y), sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], padding=1)
+def residual_conv_unit(sd: State, p: str, x: Tensor, bn: bool = False) -> Tensor:
+    """util/blocks.py:68-91: x + [bn2](conv2(relu([bn1](conv1(relu(x)))))); BatchNorm in eval mode (running statistics)."""
+    def norm(y, q):
+        if not bn:
+            return y
+        return F.batch_norm(y, sd[q + ".running_mean"], sd[q + ".running_var"], sd[q + ".weight"], sd[q + ".bias"], False, 0.0, 1e-5)
+
+    y = norm(F.conv2d(F.relu(x), sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], padding=1), p + ".bn1")
+    y = norm(F.conv2d(F.relu(y), sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], padding=1), p + ".bn2")
     return y + x
 
 
-def fusion_block(sd: State, p: str, x: Tensor, skip: Optional[Tensor], size) -> Tensor:
+def fusion_block(sd: State, p: str, x: Tensor, skip: Optional[Tensor], size, bn: bool = False) -> Tensor:
     """util/blocks.py:135-162."""
     if skip is not None:
-        x = x + residual_conv_unit(sd, p + ".resConfUnit1", skip)
-    x = residual_conv_unit(sd, p + ".resConfUnit2", x)
+        x = x + residual_conv_unit(sd, p + ".resConfUnit1", skip, bn)
+    x = residual_conv_unit(sd, p + ".resConfUnit2", x, bn)
     x = _up(x, size=size) if size is not None else _up(x, scale=2)
     return F.conv2d(x, sd[p + ".out_conv.weight"], sd[p + ".out_conv.bias"])
 
@@ -310,12 +334,12 @@ def dpt_head(sd: State, feats, ph: int, pw: int, T: int, cfg: OracleConfig, stag
     r3 = F.conv2d(l3, sd["head.scratch.layer3_rn.weight"], padding=1)
     r4 = F.conv2d(l4, sd["head.scratch.layer4_rn.weight"], padding=1)
     s = "head.scratch."
-    p4 = fusion_block(sd, s + "refinenet4", r4, None, r3.shape[2:])
+    p4 = fusion_block(sd, s + "refinenet4", r4, None, r3.shape[2:], cfg.use_bn)
     p4 = motion_module(sd, 2, p4, T, cfg)
-    p3 = fusion_block(sd, s + "refinenet3", p4, r3, r2.shape[2:])
+    p3 = fusion_block(sd, s + "refinenet3", p4, r3, r2.shape[2:], cfg.use_bn)
     p3 = motion_module(sd, 3, p3, T, cfg)
-    p2 = fusion_block(sd, s + "refinenet2", p3, r2, r1.shape[2:])
-    p1 = fusion_block(sd, s + "refinenet1", p2, r1, None)
+    p2 = fusion_block(sd, s + "refinenet2", p3, r2, r1.shape[2:], cfg.use_bn)
+    p1 = fusion_block(sd, s + "refinenet1", p2, r1, None, cfg.use_bn)
     if stages is not None:
         stages.update(path4=p4, path3=p3, path2=p2, path1=p1)
     out: Dict[Tuple[str, int], Tensor] = {}

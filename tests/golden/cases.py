@@ -30,6 +30,9 @@ CASES = {
     "micro_clstoken_nocls": (dict(VITS_SMALL_HEAD, image_shape=(42, 56), lora_type="lora", use_clstoken=True, include_cls_token=False), (1, 2, 42, 56), "uniform", "full"),
     "micro_dash": (dict(VITS_SMALL_HEAD, image_shape=(42, 56), lora_type="dash", disable_conv_head=True), (1, 2, 42, 56), "uniform", "full"),
     "micro_dash_active": (dict(VITS_SMALL_HEAD, image_shape=(42, 56), lora_type="dash", disable_conv_head=True), (1, 2, 42, 56), "uniform", "full"),
+    "micro_bn": (dict(VITS_SMALL_HEAD, image_shape=(42, 56), lora_type="dvlora", disable_conv_head=True, use_bn=True), (1, 2, 42, 56), "uniform", "full"),
+    "micro_rope": (dict(VITS_SMALL_HEAD, image_shape=(42, 56), lora_type="dvlora", disable_conv_head=True, pe="rope"), (1, 5, 42, 56), "tissue", "full"),
+    "micro_rope_bn_conv": (dict(VITS_SMALL_HEAD, image_shape=(42, 42), lora_type="lora", use_bn=True, pe="rope"), (2, 3, 42, 42), "uniform", "full"),
     # residual bottleneck blocks: the reference hard-wires their grid to 16x20 patches, i.e. image_shape (224, 280)
     "resblock_224x280": (dict(VITS_SMALL_HEAD, image_shape=(224, 280), lora_type="dvlora", residual_block_indexes=[2, 5, 8, 11]), (1, 2, 224, 280), "tissue", "strided"),
     # --- reference default geometry (224x280 from 256x320 frames, trainer_end_to_end_video.py:61)

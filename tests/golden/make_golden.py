@@ -209,6 +209,7 @@ def dump_state_keys(ref):
         "vits_dash_conv": dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384], lora_type="dash"),
         "vits_none_vda": dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384], lora_type="none", disable_conv_head=True),
         "vitl_dvlora_vda": dict(encoder="vitl", features=256, out_channels=[256, 512, 1024, 1024], lora_type="dvlora", disable_conv_head=True),
+        "vits_bn_rope": dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384], lora_type="dvlora", disable_conv_head=True, use_bn=True, pe="rope"),
         "vits_clstoken_resblocks": dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384], lora_type="dvlora", use_clstoken=True,
                                         residual_block_indexes=[2, 5, 8, 11]),
     }
@@ -259,7 +260,8 @@ def main(argv):
             r=kwargs.get("r", 4), include_cls_token=kwargs.get("include_cls_token", True),
             disable_conv_head=kwargs.get("disable_conv_head", False), inv_sigmoid=kwargs.get("inv_sigmoid", False),
             out_sigmoid=kwargs.get("out_sigmoid", False), use_clstoken=kwargs.get("use_clstoken", False),
-            residual_block_indexes=tuple(kwargs.get("residual_block_indexes", ())), dash_active=dash_active)
+            residual_block_indexes=tuple(kwargs.get("residual_block_indexes", ())), dash_active=dash_active,
+            use_bn=kwargs.get("use_bn", False), pe=kwargs.get("pe", "ape"))
         stages = {}
         with torch.no_grad():
             out_orc = orc.forward(sd, x, cfg, stages)

@@ -17,7 +17,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 def oracle_config(kwargs, dash_active: bool = False) -> orc.OracleConfig:
     return orc.OracleConfig(
         use_clstoken=kwargs.get("use_clstoken", False), residual_block_indexes=tuple(kwargs.get("residual_block_indexes", ())),
-        dash_active=dash_active,
+        dash_active=dash_active, use_bn=kwargs.get("use_bn", False), pe=kwargs.get("pe", "ape"),
         encoder=kwargs["encoder"], image_shape=tuple(kwargs["image_shape"]), lora_type=kwargs.get("lora_type", "lora"),
         r=kwargs.get("r", 4), include_cls_token=kwargs.get("include_cls_token", True),
         disable_conv_head=kwargs.get("disable_conv_head", False), inv_sigmoid=kwargs.get("inv_sigmoid", False),

@@ -258,6 +258,10 @@ def test_errors_are_loud(cuda):
     with pytest.raises(NotImplementedError):  # a trainable tensor the HIP backward has no gradient for is refused, not silently frozen
         model(x)
     model.get_parameter("head.scratch.output_conv1.weight").requires_grad = False
+    bn, _, xb, _ = run_hip("micro_bn", cuda)  # BatchNorm is folded from its running statistics: eval() only
+    with pytest.raises(NotImplementedError, match="eval"):
+        with torch.no_grad():
+            bn.train()(xb)
     # residual blocks away from the reference's hard-wired 16x20 grid: its reshape fails, so does ours
     bad = endodav_amd.endodav(encoder="vits", features=32, out_channels=[32, 32, 64, 64], image_shape=(42, 56), residual_block_indexes=[2]).to(cuda)
     with pytest.raises(RuntimeError, match="16, 20"):

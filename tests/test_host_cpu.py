@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol():
 def test_abi_version_and_config_layout():
     lib = _lib.load()
     assert lib.edv_abi_version() == _lib.ABI_VERSION
-    assert C.sizeof(_lib.EdvConfig) == 4 * 27  # 27 32-bit slots incl. the two int[4] arrays
+    assert C.sizeof(_lib.EdvConfig) == 4 * 29  # 29 32-bit slots incl. the two int[4] arrays
 
 
 def test_create_validates_config_without_gpu():
@@ -58,7 +58,7 @@ def ref_keys():
 
 
 @pytest.mark.parametrize("combo", ["vits_dvlora_vda", "vits_lora_conv", "vits_ssb_vda_tlora", "vits_dash_conv", "vits_none_vda", "vitl_dvlora_vda",
-                                   "vits_clstoken_resblocks"])
+                                   "vits_clstoken_resblocks", "vits_bn_rope"])
 def test_state_dict_keys_shapes_and_trainable_set_match_reference(ref_keys, combo):
     entry = ref_keys[combo]
     m = endodav_amd.endodav(**entry["kwargs"], pretrained_path=None)

@@ -312,6 +312,34 @@ def test_attn_temporal(lib, cuda, Bc, T, P, Cc):
     close(o, ref, 3e-6, "attn_temporal")
 
 
+@pytest.mark.parametrize("Bc,T,P,Cc", [(1, 8, 361, 384), (2, 5, 33, 64), (1, 32, 17, 192)])
+def test_rope_qk(lib, cuda, Bc, T, P, Cc):
+    """pe="rope" (attention.py:402-429, restated with torch complex arithmetic as the reference does it): q and k rotated in place,
+    v untouched; the transposed launch is the adjoint, so <R x, y> == <x, R^T y> and R^T R x == x."""
+    from endodav_amd.endodav import _rope_table
+
+    table = _rope_table(Cc, 32)  # [32, C/2, 2]
+    fc = torch.view_as_complex(table)[:T]  # [T, C/2]
+    qkv = rnd(Bc * T * P, 3 * Cc, seed=1, scale=1.5)
+    t = qkv.reshape(Bc, T, P, 3, Cc)
+    ref = t.clone()
+    for j in range(2):
+        z = torch.view_as_complex(t[:, :, :, j].reshape(Bc, T, P, Cc // 2, 2).contiguous()) * fc[None, :, None, :]
+        ref[:, :, :, j] = torch.view_as_real(z).flatten(-2)
+    ref = ref.reshape(Bc * T * P, 3 * Cc)
+    qd, td = qkv.to(cuda), table.to(cuda)
+    _lib.check(lib.edv_rope_qk(qd.data_ptr(), td.data_ptr(), Bc, T, P, Cc, 0, st()), "edv_rope_qk")
+    close(qd, ref, 1e-6, "rope")
+    assert torch.equal(qd[:, 2 * Cc:].cpu(), qkv[:, 2 * Cc:])
+    y = rnd(Bc * T * P, 3 * Cc, seed=2)
+    yd = y.to(cuda)
+    _lib.check(lib.edv_rope_qk(yd.data_ptr(), td.data_ptr(), Bc, T, P, Cc, 1, st()), "edv_rope_qk^T")
+    lhs, rhs = (qd.double().cpu() * y.double()).sum().item(), (qkv.double() * yd.double().cpu()).sum().item()
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), 1.0)
+    _lib.check(lib.edv_rope_qk(qd.data_ptr(), td.data_ptr(), Bc, T, P, Cc, 1, st()), "edv_rope_qk^T")
+    close(qd, qkv, 1e-6, "rope round trip")
+
+
 def test_attn_temporal_rejects_long_clips(lib, cuda):
     z = torch.zeros(33 * 8 * 3 * 64, device=cuda)
     assert lib.edv_attn_temporal(z.data_ptr(), z.data_ptr(), 1, 33, 8, 64, 8, st()) != 0

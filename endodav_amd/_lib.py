@@ -58,6 +58,7 @@ SIGNATURES = {
     "edv_destroy": (C.c_int, [C.c_void_p]),
     "edv_bind_param": (C.c_int, [C.c_void_p, C.c_char_p, _fp, C.POINTER(_i64), _i32]),
     "edv_prepare": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "edv_refresh_lora": (C.c_int, [C.c_void_p, C.c_void_p]),
     "edv_forward": (C.c_int, [C.c_void_p, _fp, _i32, _i32, _i32, _i32, C.POINTER(C.c_void_p), C.c_void_p]),
     "edv_output_shape": (C.c_int, [C.c_void_p, _i32, C.POINTER(_i32), C.POINTER(_i32)]),
     "edv_stage_copy": (C.c_int, [C.c_void_p, C.c_char_p, _fp, C.POINTER(C.c_size_t), C.c_void_p]),

@@ -346,6 +346,30 @@ struct Run {
         return 0;
     }
 
+    // After an optimizer step only the LoRA factors changed: re-fold the linears that carry them (and, once the backward has
+    // run, their transposes) instead of re-packing every frozen weight as edv_prepare does.
+    int refresh_lora() {
+        EDV_CHECK(c->prepared, "edv_prepare has not run");
+        for (int i = 0; i < depth; ++i) {
+            const std::string bp = "pretrained.blocks." + std::to_string(i);
+            EDV_TRY(fold_linear(bp + ".mlp.fc1", true));
+            EDV_TRY(fold_linear(bp + ".mlp.fc2", true));
+            if (c->train_prepared) {
+                const float *g2;
+                EDV_TRY(param(bp + ".ls2.gamma", &g2));
+                EDV_TRY(make_t_lin(bp + ".mlp.fc1"));
+                EDV_TRY(make_t_lin(bp + ".mlp.fc2", g2));
+            }
+        }
+        if (cfg.temporal_lora)
+            for (int m = 0; m < 4; ++m) {
+                const std::string p = "head.motion_modules." + std::to_string(m) + ".temporal_transformer.transformer_blocks.0.ff.net.2";
+                EDV_TRY(fold_linear(p, true));
+                if (c->train_prepared) EDV_TRY(make_t_lin(p));
+            }
+        return 0;
+    }
+
     // position table for the current patch grid (vision_transformer.py:186-217)
     int pos_table(const float **out) {
         const float *pos;
@@ -1500,6 +1524,12 @@ int edv_prepare(edv_ctx *ctx, void *stream) {
     EDV_CHECK(ctx, "null context");
     Run r(ctx, (hipStream_t)stream);
     return r.prepare();
+}
+
+int edv_refresh_lora(edv_ctx *ctx, void *stream) {
+    EDV_CHECK(ctx, "null context");
+    Run r(ctx, (hipStream_t)stream);
+    return r.refresh_lora();
 }
 
 int edv_set_capture(edv_ctx *ctx, int on) {

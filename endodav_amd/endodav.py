@@ -341,6 +341,11 @@ class _Head(_Holder):
                 setattr(self, f"conv_depth_{k}", HeadDepth(features))
 
 
+def _is_lora_factor(name: str) -> bool:
+    """Factors of the linears edv_refresh_lora re-folds: mlp.fc1/fc2 of the encoder blocks, ff.net.2 of the motion modules."""
+    return (".mlp.fc" in name or ".ff.net.2." in name) and name.rsplit(".", 1)[-1] in ("lora_A", "lora_B", "lora_U", "lora_V")
+
+
 class _NativeCtx:
     """Owns one ``edv_ctx`` (one device).  Destroyed with the last module/replica that references it."""
 
@@ -501,6 +506,11 @@ class endodav(nn.Module):
         if self.pe == "rope":  # the rotary tables are not state (motion_module.py:221-225) but the engine reads them like weights
             sd.update({k: v for k, v in self.named_buffers() if k.endswith(".freqs_cis")})
         sig = tuple((k, v.data_ptr(), v._version) for k, v in sd.items())
+        if sig != nat.sig and nat.sig is not None and len(sig) == len(nat.sig) and self.lora_type in ("lora", "dvlora", "ssb") and all(
+                a[:2] == b[:2] and (a[2] == b[2] or _is_lora_factor(a[0])) for a, b in zip(sig, nat.sig)):
+            # the fine-tune loop: same tensors, only LoRA factors written (optimizer.step) -> re-fold those linears only
+            _lib.check(lib.edv_refresh_lora(C.c_void_p(nat.handle), C.c_void_p(_lib.stream_ptr(device))), "edv_refresh_lora")
+            nat.sig = sig
         if sig != nat.sig:
             for k, v in sd.items():
                 if not v.is_floating_point():

@@ -64,6 +64,7 @@ struct edv_ctx {
     std::unordered_map<std::string, Buf> packed;  // derived weights, owned
     std::unordered_map<std::string, Buf> ws;      // activations, owned
     bool prepared = false;
+    const float *skws_zeroed = nullptr;  // stream-K workspace whose arrival counters have been zeroed (gemm_dma.hip)
     bool capture = false;
     bool train = false;           // forward keeps the activations the backward needs (edv_set_train)
     bool train_prepared = false;  // transposed / flipped weights of the input-gradient GEMMs are current
@@ -772,17 +773,24 @@ struct Run {
         }
         float *attws = nullptr;
         if (attws_each) EDV_TRY(wsbuf("attws", attws_each * nstreams, &attws));
-        // Stream-K for the dense GEMMs is opt-in (EDV_GEMM_STREAMK=1): with four co-resident 64x64-tile workgroups per CU
-        // the statically assigned persistent form measures neutral against the plain grid (qkv T=8 113.7 vs 109.9 us,
-        // fc2 147.0 vs 151.5): the SIMD issues oldest-wave-first, the workgroups of a CU run at very different speeds, and
-        // what the split saves on the tail is lost in balance (profiles/r01_gemm_tile_sweep.txt).
+        // Stream-K for the dense GEMMs (gemm_dma.hip): the last partial round of output tiles is split along K over the resident
+        // workgroups and merged in-kernel by the last piece to arrive.  One workspace region per stream that launches GEMMs
+        // concurrently: the encoder's frame-group streams, and the head's caller / internal stream pair (regions 0 and 1).
+        // EDV_GEMM_STREAMK=0 restores one workgroup per tile.
         static const bool gemm_streamk = [] {
             const char *e = getenv("EDV_GEMM_STREAMK");
-            return e && atoi(e) != 0;
+            return !(e && atoi(e) == 0);
         }();
         const size_t skws_each = gemm_streamk ? gemm_workspace() : 0;
+        const int skws_regions = nstreams > 2 ? nstreams : 2;
         float *skws_all = nullptr;
-        if (skws_each) EDV_TRY(wsbuf("skws", skws_each * nstreams, &skws_all));
+        if (skws_each) {
+            EDV_TRY(wsbuf("skws", skws_each * skws_regions, &skws_all));
+            if (c->skws_zeroed != skws_all) {  // fresh allocation: the arrival counters at the head of each region start at zero
+                for (int h = 0; h < skws_regions; ++h) EDV_HIP(hipMemsetAsync(skws_all + (size_t)h * skws_each, 0, gemm_counter_bytes(), st));
+                c->skws_zeroed = skws_all;
+            }
+        }
         EncBufs eb{cols, xt, xn, qkv, att, hid, {tap[0], tap[1], tap[2], tap[3]}, {tapcls[0], tapcls[1], tapcls[2], tapcls[3]}, pos, attws, attws_each,
                    skws_all, skws_each};
         skws = skws_all;  // the head runs on the caller's stream with region 0 (the encoder streams have joined by then)
@@ -921,11 +929,12 @@ struct Run {
             EDV_TRY(wsbuf("fu.u2", (size_t)F * h2 * w2 * Fe, &u2));
             EDV_TRY(wsbuf("fu.u3", (size_t)F * h3 * w3 * Fe, &u3));
             hipStream_t user = st, side = c->sub[0];
+            float *const ws_user = skws, *const ws_side = skws ? skws + skws_floats : nullptr;  // stream-K regions 0 and 1
             EDV_HIP(hipEventRecord(c->ev_fork, user));
             EDV_HIP(hipStreamWaitEvent(side, c->ev_fork, 0));
-            st = side;
+            st = side; skws = ws_side;
             int rc = level(3);
-            st = user;
+            st = user; skws = ws_user;
             if (rc) return rc;
             EDV_HIP(hipEventRecord(c->ev_join[0], side));     // r4 ready
             EDV_TRY(level(2));
@@ -942,20 +951,20 @@ struct Run {
             } else {
                 EDV_HIP(hipEventRecord(c->ev_x[0], user));        // r3 ready
                 EDV_HIP(hipStreamWaitEvent(side, c->ev_x[0], 0));
-                st = side;
+                st = side; skws = ws_side;
                 rc = fusion_skip_branch(3, r3, h3, w3, u3);
-                st = user;
+                st = user; skws = ws_user;
                 if (rc) return rc;
                 EDV_HIP(hipEventRecord(c->ev_x[2], side));        // u3 ready
                 EDV_TRY(level(0));
                 EDV_TRY(level(1));
                 EDV_HIP(hipEventRecord(c->ev_x[1], user));        // r1, r2 ready
                 EDV_HIP(hipStreamWaitEvent(side, c->ev_x[1], 0));
-                st = side;
+                st = side; skws = ws_side;
                 rc = fusion_skip_branch(2, r2, h2, w2, u2);
                 if (!rc) EDV_HIP(hipEventRecord(c->ev_x[3], side));  // u2 ready
                 if (!rc) rc = fusion_skip_branch(1, r1, h1, w1, u1);
-                st = user;
+                st = user; skws = ws_user;
                 if (rc) return rc;
                 EDV_HIP(hipEventRecord(c->ev_x[4], side));        // u1 ready
                 EDV_HIP(hipStreamWaitEvent(user, c->ev_join[0], 0));

@@ -30,18 +30,26 @@ namespace {
 constexpr int DBK = 32, DBM = 64, DBN = 64;
 constexpr int DSTAGE = (DBM + DBN) * DBK;  // floats per stage (16 KB)
 
-// Work split of one launch (host-made, passed by value).  G = gridDim.x persistent workgroups, all co-resident.
-// Every workgroup first computes `whole_rounds` whole output tiles (tile = round * G + id), then its share
-// [id * chunk, (id + 1) * chunk) of the `units` = leftover_tiles * k_tiles key-tile units of the remaining
-// tiles % G tiles.  A run that does not cover a tile's whole k range leaves its raw accumulators in workspace slot
-// (id * 2 + run) and gemm_fixup_kernel sums the pieces and applies the epilogue.  Without a workspace the launch is the
-// plain grid: G = tiles, one whole tile each.
+// Work split of one launch (host-made, passed by value).  G = gridDim.x persistent workgroups, all co-resident (4 per CU: what
+// 32 KB of LDS really places, scratch/ubench/lds_residency.hip).  Every workgroup first computes `whole_rounds` whole output tiles
+// (tile = round * G + id).  The remaining tiles % G tiles are `units` = leftover_tiles * k_tiles k-tile units; they are cut into
+// `nsplit` contiguous runs of `chunk` units, run j going to the workgroup with id j * stride (spread over the CUs).  A run that
+// does not cover a tile's whole k range leaves its raw accumulators in workspace slot (j * 2 + segment), bumps the tile's
+// arrival counter, and the LAST run to arrive sums all pieces of that tile in run order (so the result does not depend on the
+// arrival order) and applies the epilogue: no fix-up launch, no spinning.  The counters live at the head of the workspace, must
+// be zero before the first launch, and are left zero by every launch.  Without a workspace the launch is the plain grid:
+// G = tiles, one whole tile each.
+//
+// Why it matters (profiles/r01_gemm_tile_sweep.txt, warm clocks): a CU retires tiles at a fixed MFMA-bound rate, so a grid of
+// 1032 tiles on 256 CUs (N = 384 at 8 x 1370 rows) takes as long as 1280 tiles: fc2 138 us vs 112 us at 1020 tiles.
 struct GemmSplit {
-    int whole_rounds, chunk;
+    int whole_rounds, chunk, nsplit, stride;
     long long units;
-    float *ws;
+    float *ws;   // slots (after the counters)
+    int *cnt;    // one arrival counter per leftover tile
 };
-constexpr int SLOT = DBM * DBN;  // floats per workspace slot; element (wave, r, lane) at (wave * 16 + r) * 64 + lane
+constexpr int SLOT = DBM * DBN;   // floats per workspace slot; element (wave, r, lane) at (wave * 16 + r) * 64 + lane
+constexpr int MAX_COUNTERS = 4096;  // >= resident slots of any CDNA4 part (leftover tiles < slots)
 
 template <int STORE, int EP>
 __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g, const GemmSplit sp) {
@@ -58,11 +66,13 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g, const G
     const int swa = (ra >> 1) & 7, swb = (rb >> 1) & 7;
 
     const int tile_l0 = sp.whole_rounds * G;
-    long long u = (long long)bid * sp.chunk;
-    const long long u_end = u + sp.chunk < sp.units ? u + sp.chunk : sp.units;
+    // run j = bid / stride of the split (only workgroups with bid % stride == 0 and j < nsplit own one)
+    const int run = (sp.units > 0 && bid % sp.stride == 0 && bid / sp.stride < sp.nsplit) ? bid / sp.stride : -1;
+    long long u = run >= 0 ? (long long)run * sp.chunk : 0;
+    const long long u_end = run >= 0 ? (u + sp.chunk < sp.units ? u + sp.chunk : sp.units) : 0;
     int round = 0, seg = 0;
     for (;;) {
-        int tile, kt0, kt1;
+        int tile, kt0, kt1, lt = 0;
         float *part = nullptr;
         if (round < sp.whole_rounds) {
             tile = round * G + bid;
@@ -75,9 +85,10 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g, const G
             const long long left = u_end - u;
             kt1 = kt0 + left < nkt ? kt0 + (int)left : nkt;
             tile = tile_l0 + t;
+            lt = t;
             u += kt1 - kt0;
-            if (!(kt0 == 0 && kt1 == nkt)) part = sp.ws + ((long long)bid * 2 + seg) * SLOT;
-            ++seg;  // slot 0 = the run holding this workgroup's first unit, slot 1 = the head of the next tile
+            if (!(kt0 == 0 && kt1 == nkt)) part = sp.ws + ((long long)run * 2 + seg) * SLOT;
+            ++seg;  // slot 0 = the piece holding this run's first unit, slot 1 = the head of the next tile
         } else {
             break;
         }
@@ -140,34 +151,57 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g, const G
         }
         EDV_GEMM_STAMP(3);
         if (part) {
+            // Pieces travel between workgroups on different XCDs (separate L2s).  An agent-scope release / acquire fence pair
+            // would do it, but on this part the release writes back the WHOLE L2 (buffer_wbl2) -- measured +140 us per launch
+            // with every other workgroup's output tiles dirty in it.  Instead the piece itself is written and read with
+            // agent-scope relaxed atomics = write-through stores / L2-bypassing loads (sc1), and the arrival is counted after
+            // s_waitcnt vmcnt(0) has seen those stores acknowledged.
 #pragma unroll
-            for (int r = 0; r < 16; ++r) part[(wave * 16 + r) * 64 + lane] = acc[0][0][r];
+            for (int r = 0; r < 16; ++r) __hip_atomic_store(&part[(wave * 16 + r) * 64 + lane], acc[0][0][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // pieces of leftover tile lt: the runs whose unit ranges intersect [lt * nkt, (lt + 1) * nkt)
+            const long long ub = (long long)lt * nkt;
+            const int g0 = (int)(ub / sp.chunk), g1 = (int)((ub + nkt - 1) / sp.chunk);
+            int *s_last = reinterpret_cast<int *>(smem);  // both LDS stages are idle between the k loop and the next tile's first DMA
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const int arrived = __hip_atomic_fetch_add(&sp.cnt[lt], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = arrived == g1 - g0;
+                if (last) __hip_atomic_store(&sp.cnt[lt], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // all pieces in: zero for the next launch
+                *s_last = last;
+            }
+            __syncthreads();
+            const bool last = *s_last != 0;
+            __syncthreads();  // s_last is read before the next tile's DMA may overwrite it
+            if (last) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+                const float *base = sp.ws + (wave * 16) * 64 + lane;
+                int gg = g0;
+                for (; gg + 1 <= g1; gg += 2) {  // two pieces in flight; summed in run order whatever the arrival order was
+                    const float *pa = base + ((long long)gg * 2 + ((long long)gg * sp.chunk >= ub ? 0 : 1)) * SLOT;
+                    const float *pb = base + ((long long)(gg + 1) * 2 + ((long long)(gg + 1) * sp.chunk >= ub ? 0 : 1)) * SLOT;
+                    float ta[16], tb[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        ta[r] = __hip_atomic_load(pa + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        tb[r] = __hip_atomic_load(pb + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][0][r] = (acc[0][0][r] + ta[r]) + tb[r];
+                }
+                if (gg <= g1) {
+                    const float *pa = base + ((long long)gg * 2 + ((long long)gg * sp.chunk >= ub ? 0 : 1)) * SLOT;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][0][r] += __hip_atomic_load(pa + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                gemm_epilogue_ep<1, 1, STORE, EP>(g, acc, cols, m0, n0, wm * 32, wn * 32, l31, lh);
+            }
         } else {
             gemm_epilogue_ep<1, 1, STORE, EP>(g, acc, cols, m0, n0, wm * 32, wn * 32, l31, lh);
         }
         EDV_GEMM_STAMP(4);
     }
-}
-
-// Sums the pieces of every split tile and applies the epilogue.  Pieces of leftover tile t: the workgroups whose unit
-// runs intersect [t * nkt, (t + 1) * nkt); a workgroup's piece is in its slot 0 when its first unit lies in this tile.
-template <int STORE>
-__global__ __launch_bounds__(256) void gemm_fixup_kernel(const GemmDesc g, const GemmSplit sp, int tile_l0) {
-    const int nkt = g.K / DBK;
-    const int t = blockIdx.x;
-    const long long ub = (long long)t * nkt, ue = ub + nkt;
-    const int g0 = (int)(ub / sp.chunk), g1 = (int)((ue - 1) / sp.chunk);
-    if (g0 == g1 && (long long)g0 * sp.chunk <= ub && (long long)(g0 + 1) * sp.chunk >= ue) return;  // ran whole
-    const int e = blockIdx.y * 256 + threadIdx.x;  // element of the 64 x 64 tile in accumulator order
-    float v = 0.f;
-    for (int gg = g0; gg <= g1; ++gg) v += sp.ws[((long long)gg * 2 + ((long long)gg * sp.chunk >= ub ? 0 : 1)) * SLOT + e];
-    const int lane = e & 63, r = (e >> 6) & 15, wave = e >> 10;
-    const int tiles_n = (g.N + DBN - 1) / DBN;
-    const int tile = tile_l0 + t;
-    const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
-    const long long m = (long long)tm * DBM + (wave >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-    const int n = tn * DBN + (wave & 1) * 32 + (lane & 31);
-    if (m < g.M && n < g.N) gemm_epilogue_elem<STORE>(g, v, m, n);
 }
 
 template <int STORE, int EP>
@@ -194,27 +228,37 @@ int launch_dma(const GemmDesc &d, long long tiles, hipStream_t st) {
         const char *e = getenv("EDV_GEMM_PLAIN");  // 1: one workgroup per tile even with a workspace (A/B runs)
         return e && atoi(e) != 0;
     }();
-    GemmSplit sp{1, 1, 0, nullptr};
+    GemmSplit sp{1, 1, 0, 1, 0, nullptr, nullptr};
     long long grid = tiles;
     const int slots = dma_slots<STORE, EP>();
-    EDV_CHECK(slots > 0, "occupancy query failed");
-    // worth splitting only when the grid is a few rounds deep: beyond that the tail is a small fraction
-    if (d.ws && !plain_forced && tiles > slots / 2 && tiles < 16ll * slots) {
+    EDV_CHECK(slots > 0 && slots <= MAX_COUNTERS, "occupancy query failed");
+    const long long left = tiles % slots;
+    // worth splitting only when the grid is a few rounds deep (beyond ~5 the last round is a small fraction and the persistent
+    // form's 1-2 % deficit outweighs it: ViT-L fc2 at T=32, 10.7 rounds, measures -2 %)
+    static const int min_kt = [] {
+        const char *e = getenv("EDV_GEMM_SPLIT_MIN_KT");  // k-tiles per tile from which the split is used (A/B runs)
+        return e ? atoi(e) : 24;
+    }();
+    // ... and the tiles are deep: statically assigned persistent workgroups lose 1-10 % against the hardware's dynamic dispatch
+    // of the plain grid when a tile is only 12 k-tiles long (K = 384), and win 5-15 % from K = 768 up (warm A/B in
+    // profiles/r01_gemm_tile_sweep.txt)
+    if (d.ws && !plain_forced && left > 0 && tiles > slots / 2 && tiles < 5ll * slots && d.K / DBK >= min_kt) {
+        const int nkt = d.K / DBK;
         sp.whole_rounds = (int)(tiles / slots);
-        const long long left = tiles - (long long)sp.whole_rounds * slots;
-        sp.units = left * (d.K / DBK);
-        sp.chunk = sp.units ? (int)((sp.units + slots - 1) / slots) : 1;
-        sp.ws = d.ws;
-        grid = sp.whole_rounds ? slots : (sp.units + sp.chunk - 1) / sp.chunk;
-        const long long split_wgs = (sp.units + sp.chunk - 1) / sp.chunk;
-        EDV_CHECK((size_t)split_wgs * 2 * SLOT <= d.ws_floats && (uintptr_t)d.ws % 16 == 0, "stream-K workspace too small (gemm_workspace)");
-        hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
-        EDV_LAUNCH_OK();
-        if (left) {
-            hipLaunchKernelGGL((gemm_fixup_kernel<STORE>), dim3((unsigned)left, SLOT / 256), dim3(256), 0, st, d, sp, sp.whole_rounds * slots);
-            EDV_LAUNCH_OK();
-        }
-        return 0;
+        sp.units = left * nkt;
+        // run length: an even share of the units, but no shorter than 1/4 of a tile's k range (<= ~5 pieces to merge per tile:
+        // the merge is a chain of L2-bypassing loads at the very end of the launch)
+        long long chunk = (sp.units + slots - 1) / slots;
+        const long long chunk_min = (nkt + 3) / 4;
+        chunk = chunk > chunk_min ? chunk : chunk_min;
+        sp.chunk = (int)chunk;
+        sp.nsplit = (int)((sp.units + chunk - 1) / chunk);
+        grid = sp.whole_rounds ? slots : (sp.nsplit > 0 ? sp.nsplit : 1);
+        sp.stride = (int)(grid / sp.nsplit) > 0 ? (int)(grid / sp.nsplit) : 1;
+        sp.cnt = reinterpret_cast<int *>(d.ws);
+        sp.ws = d.ws + MAX_COUNTERS;
+        EDV_CHECK((size_t)MAX_COUNTERS + (size_t)sp.nsplit * 2 * SLOT <= d.ws_floats && (uintptr_t)d.ws % 16 == 0,
+                  "stream-K workspace too small (gemm_workspace)");
     }
     hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
     EDV_LAUNCH_OK();
@@ -226,8 +270,10 @@ int launch_dma(const GemmDesc &d, long long tiles, hipStream_t st) {
 size_t gemm_workspace() {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    return (size_t)cus * 8 * 2 * SLOT;  // at most 8 co-resident workgroups per CU (LDS: 32 KB each), two slots each
+    return (size_t)MAX_COUNTERS + (size_t)cus * 8 * 2 * SLOT;  // arrival counters + two slots for each of at most 8 workgroups per CU
 }
+
+size_t gemm_counter_bytes() { return (size_t)MAX_COUNTERS * sizeof(int); }
 
 bool gemm_dma_supported(const GemmDesc &d) {
     return d.loader == LOAD_DENSE && d.K % DBK == 0 && d.lda % 4 == 0 && d.ldw % 4 == 0 && d.M > 0 && d.N > 0;

@@ -47,13 +47,15 @@ struct GemmDesc {
     int cH = 0, cW = 0, cC = 0, cOH = 0, cOW = 0, cS = 1, pre_relu = 0;
     int store = STORE_ROWS;
     int ps_s = 0, ps_C = 0, ps_h = 0, ps_w = 0;
-    // stream-K split workspace (gemm_workspace() floats, 16-byte aligned, one per concurrently running GEMM);
+    // stream-K split workspace (gemm_workspace() floats, 16-byte aligned, one per concurrently running GEMM; its first
+    // gemm_counter_bytes() must be zero before the first launch and are left zero by every launch);
     // nullptr = plain grid, one workgroup per output tile
     float *ws = nullptr;
     size_t ws_floats = 0;
 };
 int gemm(const GemmDesc &d, hipStream_t st);
 size_t gemm_workspace();  // floats; enough for any shape on the current device
+size_t gemm_counter_bytes();  // the zero-initialised arrival counters at the head of the workspace
 // LDS-DMA staged variant (gemm_dma.hip): dense A, K % 32 == 0; picked by gemm() for small/medium grids.
 bool gemm_dma_supported(const GemmDesc &d);
 int gemm_dma(const GemmDesc &d, hipStream_t st);

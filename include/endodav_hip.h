@@ -136,9 +136,11 @@ int edv_layernorm(const float *x_dev, const float *w_dev, const float *b_dev, fl
  * F.linear / 1x1 conv with the epilogues of block.py:144-145, mlp.py:34-37. */
 int edv_gemm(const float *A_dev, const float *W_dev, float *C_dev, int64_t M, int32_t N, int32_t K, const float *bias_dev,
              int32_t act, const float *gamma_dev, const float *R_dev, float *workspace_dev, size_t workspace_bytes, void *stream);
-/* Stream-K workspace for edv_gemm, in BYTES (one size fits every shape on this device).  With a workspace the GEMM runs
- * as persistent workgroups that split the last partial round of output tiles along K and merge the pieces in a fix-up
- * kernel; with workspace_dev = NULL it runs one workgroup per tile.  Same results up to fp32 summation order. */
+/* Stream-K workspace for edv_gemm, in BYTES (one size fits every shape on this device; one workspace per concurrently running
+ * GEMM).  With a workspace the GEMM runs as persistent workgroups that split the last partial round of output tiles along K;
+ * the last piece of a tile to arrive merges the pieces in a fixed order and applies the epilogue (no second launch; same
+ * results up to fp32 summation order, reproducible run to run).  The workspace must be ZERO-FILLED once before its first use
+ * (it starts with per-tile arrival counters, which every launch leaves at zero).  workspace_dev = NULL: one workgroup per tile. */
 size_t edv_gemm_workspace(void);
 
 /* Split-bf16 variant of edv_gemm: fp32-equivalent accuracy from six v_mfma_f32_32x32x16_bf16 per product (each

@@ -4,7 +4,7 @@ from endodav_amd import _lib
 lib = _lib.load()
 import os as _os
 import torch as _t
-GWS = _t.empty(lib.edv_gemm_workspace() // 4 if not _os.environ.get('KB_NO_WS') else 4, device='cuda:0'); dev = torch.device("cuda:0")
+GWS = _t.zeros(lib.edv_gemm_workspace() // 4 if not _os.environ.get('KB_NO_WS') else 4, device='cuda:0'); dev = torch.device("cuda:0")
 st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
 def gemm(M, N, K, reps=2, act=0):
     A = torch.randn(M, K, device=dev); W = torch.randn(N, K, device=dev) * 0.05; Cm = torch.empty(M, N, device=dev); b = torch.randn(N, device=dev)

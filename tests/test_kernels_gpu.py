@@ -55,12 +55,19 @@ def test_layernorm_with_temporal_pe(lib, cuda):
 _WS = {}
 
 
+COUNTER_FLOATS = 4096  # MAX_COUNTERS of gemm_dma.hip
+
+
 def gemm_ws(lib, cuda):
-    """The stream-K workspace edv_gemm_workspace() asks for, poisoned once (pieces nobody wrote would show as NaN)."""
+    """The stream-K workspace edv_gemm_workspace() asks for.  The contract is "zero-filled once"; here only the arrival counters
+    at its head (COUNTER_FLOATS 32-bit words, gemm_dma.hip) are zeroed and the piece slots are poisoned, so that a piece nobody
+    wrote would show as NaN."""
     if "ws" not in _WS:
         nbytes = lib.edv_gemm_workspace()
         assert nbytes > 0 and nbytes % 16 == 0
-        _WS["ws"] = (torch.full((nbytes // 4,), float("nan"), device=cuda), nbytes)
+        w = torch.full((nbytes // 4,), float("nan"), device=cuda)
+        w[:COUNTER_FLOATS] = 0
+        _WS["ws"] = (w, nbytes)
     return _WS["ws"]
 
 
@@ -79,6 +86,10 @@ def gemm_ws(lib, cuda):
     (8 * 1370, 384, 384, 0, True, True, True),        # proj at T=8: 1032 tiles, one round + 8 tiles split along K
     (8 * 1370, 384, 1536, 0, True, True, True),       # fc2 at T=8: 48 k-tiles per split tile
     (700 * 64, 64, 64, 2, True, False, True),         # 2 k-tiles per tile: pieces of a single k-tile
+    (8 * 1370, 1152, 384, 0, True, False, False),     # qkv at T=8: three whole rounds + 24 tiles split
+    (4 * 1370, 1152, 384, 0, True, False, False),     # one frame group of the encoder: 524 leftover tiles, runs straddle tile boundaries
+    (4 * 1370, 384, 1536, 0, True, True, True),       # 516 tiles, no whole round: every tile is split
+    (4 * 1370, 1536, 384, 1, True, False, False),     # fc1 + GELU applied by the last piece to arrive
 ])
 @pytest.mark.parametrize("split", [False, True], ids=["plain", "streamk"])
 def test_gemm(lib, cuda, M, N, K, act, use_bias, use_gamma, use_res, split):
@@ -159,6 +170,25 @@ def test_gemm_inplace_residual(lib, cuda, M, split):
     Ad, Wd, Xd = A.to(cuda), W.to(cuda), X.to(cuda)
     _lib.check(lib.edv_gemm(Ad.data_ptr(), Wd.data_ptr(), Xd.data_ptr(), M, N, K, None, 0, None, Xd.data_ptr(), _lib.ptr(ws), nbytes, st()))
     close(Xd, ref, 3e-6, "in-place residual")
+
+
+def test_gemm_streamk_is_reproducible_and_leaves_counters_zero(lib, cuda):
+    """The in-kernel merge sums a tile's pieces in run order whatever order they arrived in: two launches give identical bits;
+    every launch leaves the arrival counters at zero (the next launch depends on it)."""
+    ws, nbytes = gemm_ws(lib, cuda)
+    for M, N, K in ((8 * 1370, 384, 1536), (4 * 1370, 1152, 384), (8 * 1370, 1536, 384)):
+        A, W = rnd(M, K, seed=1).to(cuda), rnd(N, K, seed=2, scale=1 / math.sqrt(K)).to(cuda)
+        outs = []
+        for _ in range(3):
+            Cd = torch.full((M, N), float("nan"), device=cuda)
+            _lib.check(lib.edv_gemm(A.data_ptr(), W.data_ptr(), Cd.data_ptr(), M, N, K, None, 0, None, None, ws.data_ptr(), nbytes, st()), "edv_gemm")
+            torch.cuda.synchronize()
+            assert int(ws[:COUNTER_FLOATS].view(torch.int32).abs().sum()) == 0
+            outs.append(Cd)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+        plain = torch.empty_like(outs[0])
+        _lib.check(lib.edv_gemm(A.data_ptr(), W.data_ptr(), plain.data_ptr(), M, N, K, None, 0, None, None, None, 0, st()), "edv_gemm")
+        close(outs[0], plain.double().cpu(), 2e-6, "stream-K vs plain")
 
 
 def test_gemm_rejects_bad_k(lib, cuda):

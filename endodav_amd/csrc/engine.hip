@@ -776,10 +776,12 @@ struct Run {
         // Stream-K for the dense GEMMs (gemm_dma.hip): the last partial round of output tiles is split along K over the resident
         // workgroups and merged in-kernel by the last piece to arrive.  One workspace region per stream that launches GEMMs
         // concurrently: the encoder's frame-group streams, and the head's caller / internal stream pair (regions 0 and 1).
-        // EDV_GEMM_STREAMK=0 restores one workgroup per tile.
+        // Opt-in (EDV_GEMM_STREAMK=1): in isolation the split wins 3-17 % on the deep-K GEMMs (fc2 at T=8: 137 -> 122 us with
+        // warm clocks), but inside the forward the same launches measure 138 vs 134 us by rocprofv3 and the step is within
+        // +-0.5 % either way on ViT-S T=4/8/16, ViT-B T=8/16 and the fine-tune step (profiles/r01_gemm_tile_sweep.txt).
         static const bool gemm_streamk = [] {
             const char *e = getenv("EDV_GEMM_STREAMK");
-            return !(e && atoi(e) == 0);
+            return e && atoi(e) != 0;
         }();
         const size_t skws_each = gemm_streamk ? gemm_workspace() : 0;
         const int skws_regions = nstreams > 2 ? nstreams : 2;

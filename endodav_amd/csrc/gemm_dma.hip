@@ -51,7 +51,10 @@ struct GemmSplit {
 constexpr int SLOT = DBM * DBN;   // floats per workspace slot; element (wave, r, lane) at (wave * 16 + r) * 64 + lane
 constexpr int MAX_COUNTERS = 4096;  // >= resident slots of any CDNA4 part (leftover tiles < slots)
 
-template <int STORE, int EP>
+// SPLIT = false is the plain grid (one whole tile per workgroup): the split bookkeeping and the merge compile away, which
+// keeps the hot instantiation at 48 VGPRs and its code in the instruction cache (with the merge inlined the same launches ran
+// 2 % slower end to end).
+template <int STORE, int EP, bool SPLIT>
 __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g, const GemmSplit sp) {
     __shared__ __attribute__((aligned(16))) float smem[2 * DSTAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g, const G
 
     const int tile_l0 = sp.whole_rounds * G;
     // run j = bid / stride of the split (only workgroups with bid % stride == 0 and j < nsplit own one)
-    const int run = (sp.units > 0 && bid % sp.stride == 0 && bid / sp.stride < sp.nsplit) ? bid / sp.stride : -1;
+    const int run = (SPLIT && sp.units > 0 && bid % sp.stride == 0 && bid / sp.stride < sp.nsplit) ? bid / sp.stride : -1;
     long long u = run >= 0 ? (long long)run * sp.chunk : 0;
     const long long u_end = run >= 0 ? (u + sp.chunk < sp.units ? u + sp.chunk : sp.units) : 0;
     int round = 0, seg = 0;
@@ -79,7 +82,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g, const G
             kt0 = 0;
             kt1 = nkt;
             ++round;
-        } else if (u < u_end) {
+        } else if (SPLIT && u < u_end) {
             const int t = (int)(u / nkt);
             kt0 = (int)(u - (long long)t * nkt);
             const long long left = u_end - u;
@@ -150,7 +153,8 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g, const G
             __builtin_amdgcn_s_barrier();
         }
         EDV_GEMM_STAMP(3);
-        if (part) {
+        bool finish = true;  // this workgroup applies the epilogue of the tile
+        if (SPLIT && part) {
             // Pieces travel between workgroups on different XCDs (separate L2s).  An agent-scope release / acquire fence pair
             // would do it, but on this part the release writes back the WHOLE L2 (buffer_wbl2) -- measured +140 us per launch
             // with every other workgroup's output tiles dirty in it.  Instead the piece itself is written and read with
@@ -173,6 +177,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g, const G
             __syncthreads();
             const bool last = *s_last != 0;
             __syncthreads();  // s_last is read before the next tile's DMA may overwrite it
+            finish = last;
             if (last) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
@@ -195,11 +200,9 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g, const G
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[0][0][r] += __hip_atomic_load(pa + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                gemm_epilogue_ep<1, 1, STORE, EP>(g, acc, cols, m0, n0, wm * 32, wn * 32, l31, lh);
             }
-        } else {
-            gemm_epilogue_ep<1, 1, STORE, EP>(g, acc, cols, m0, n0, wm * 32, wn * 32, l31, lh);
         }
+        if (finish) gemm_epilogue_ep<1, 1, STORE, EP>(g, acc, cols, m0, n0, wm * 32, wn * 32, l31, lh);
         EDV_GEMM_STAMP(4);
     }
 }
@@ -210,7 +213,7 @@ int dma_slots() {
         int dev = 0, cus = 0, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess) return 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_dma_kernel<STORE, EP>, 256, 0) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_dma_kernel<STORE, EP, true>, 256, 0) != hipSuccess) return 0;
         // The occupancy API answers 5 (5 x 32 KB = the whole 160 KB of LDS), the hardware places 4: the timeline of
         // scratch/ubench/gemm_trace.hip shows exactly 4 x 256 workgroups alive.  A persistent grid must match what is really
         // resident, or the surplus workgroups start only when others finish.  EDV_GEMM_SLOTS_PER_CU overrides.
@@ -259,8 +262,11 @@ int launch_dma(const GemmDesc &d, long long tiles, hipStream_t st) {
         sp.ws = d.ws + MAX_COUNTERS;
         EDV_CHECK((size_t)MAX_COUNTERS + (size_t)sp.nsplit * 2 * SLOT <= d.ws_floats && (uintptr_t)d.ws % 16 == 0,
                   "stream-K workspace too small (gemm_workspace)");
+        hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP, true>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
+        EDV_LAUNCH_OK();
+        return 0;
     }
-    hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
+    hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP, false>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
     EDV_LAUNCH_OK();
     return 0;
 }

@@ -11,7 +11,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EDV_LIB_PATH") or os.path.join(_HERE, "lib", "libendodav_hip.so")  # override: experiments only
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 LORA_TYPES = {"none": 0, "lora": 1, "dvlora": 2, "ssb": 3, "dash": 4}
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_SIGMOID_NEG = 0, 1, 2, 3, 4
@@ -81,7 +81,7 @@ SIGNATURES = {
     "edv_attn_spatial_workspace": (C.c_size_t, [_i32, _i32, _i32]),
     "edv_attn_spatial": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _fp, C.c_size_t, _fp, C.c_void_p]),
     "edv_set_train": (C.c_int, [C.c_void_p, _i32]),
-    "edv_set_grad_scope": (C.c_int, [C.c_void_p, _i32, _i32]),
+    "edv_set_grad_scope": (C.c_int, [C.c_void_p, _i32, _i32, _i32]),
     "edv_backward": (C.c_int, [C.c_void_p, _fp, C.POINTER(C.c_void_p), C.c_void_p]),
     "edv_grad": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(_i64)]),
     "edv_grad_copy": (C.c_int, [C.c_void_p, C.c_char_p, _fp, _i64, C.c_void_p]),
@@ -94,7 +94,11 @@ SIGNATURES = {
     "edv_lora_grads_workspace": (C.c_size_t, [_i64, _i32, _i32, _i32]),
     "edv_lora_grads": (C.c_int, [_fp, _fp, _i64, _i32, _i32, _i32, _fp, _fp, _fp, _fp, C.c_float, _fp, _fp, C.c_size_t, _fp, _fp, _fp, _fp, C.c_void_p]),
     "edv_bilinear_bwd": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
-    "edv_dot_channels_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i64, _i32, C.c_void_p]),
+    "edv_dot_channels_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _i64, _i32, _i32, C.c_void_p]),
+    "edv_conv3x3_wgrad_workspace": (C.c_size_t, [_i32, _i32, _i32, _i32, _i32]),
+    "edv_conv3x3_wgrad": (C.c_int, [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _fp, C.c_size_t, _i32, C.c_void_p]),
+    "edv_colsum_workspace": (C.c_size_t, [_i32]),
+    "edv_colsum_rows": (C.c_int, [_fp, _fp, _i64, _i32, _fp, C.c_size_t, _fp, _i32, C.c_void_p]),
     "edv_groupnorm_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
     "edv_attn_temporal_bwd": (C.c_int, [_fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
     "edv_pack_conv3x3_bwd": (C.c_int, [_fp, _fp, _i32, _i32, C.c_void_p]),

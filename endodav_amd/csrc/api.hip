@@ -111,9 +111,21 @@ int edv_bilinear_bwd(const float *dy_dev, float *dx_dev, int32_t F, int32_t ih, 
                      void *stream) {
     return bilinear_bwd(dy_dev, dx_dev, F, ih, iw, C, oh, ow, accumulate != 0, (hipStream_t)stream);
 }
-int edv_dot_channels_bwd(const float *g_dev, const float *disp_dev, const float *w_dev, const float *o2_dev, float *d_o2_dev, int64_t npix, int32_t C,
-                         void *stream) {
-    return dot_channels_bwd(g_dev, disp_dev, w_dev, o2_dev, d_o2_dev, npix, C, (hipStream_t)stream);
+int edv_dot_channels_bwd(const float *g_dev, const float *disp_dev, const float *w_dev, const float *o2_dev, float *d_o2_dev, float *gz_out_dev,
+                         int64_t npix, int32_t C, int32_t mode, void *stream) {
+    return dot_channels_bwd(g_dev, disp_dev, w_dev, o2_dev, d_o2_dev, gz_out_dev, npix, C, mode, (hipStream_t)stream);
+}
+size_t edv_conv3x3_wgrad_workspace(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t Cout) {
+    return conv3_wgrad_workspace(F, H, W, Cin, Cout) * sizeof(float);
+}
+int edv_conv3x3_wgrad(const float *x_dev, const float *dy_dev, float *dw_dev, int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                      float *workspace_dev, size_t workspace_bytes, int32_t accumulate, void *stream) {
+    return conv3_wgrad(x_dev, dy_dev, dw_dev, F, H, W, Cin, Cout, workspace_dev, workspace_bytes / sizeof(float), accumulate != 0, (hipStream_t)stream);
+}
+size_t edv_colsum_workspace(int32_t N) { return colsum_workspace(N) * sizeof(float); }
+int edv_colsum_rows(const float *P_dev, const float *rowscale_dev, int64_t M, int32_t N, float *workspace_dev, size_t workspace_bytes, float *out_dev,
+                    int32_t accumulate, void *stream) {
+    return colsum_rows(P_dev, rowscale_dev, M, N, workspace_dev, workspace_bytes / sizeof(float), out_dev, accumulate != 0, (hipStream_t)stream);
 }
 int edv_groupnorm_bwd(const float *x_dev, const float *stats_dev, const float *w_dev, const float *dy_dev, float *sums_dev, float *dx_dev, int32_t F,
                       int32_t P, int32_t C, int32_t groups, int32_t accumulate, void *stream) {

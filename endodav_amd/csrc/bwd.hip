@@ -311,16 +311,27 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const float *__restri
     for (int e = 0; e < V; ++e) q[e] = accumulate ? q[e] + acc[e] : acc[e];
 }
 
-// final 1x1 conv to one channel + ReLU (resample.hip dot_channels), input o2 is itself post-ReLU:
-//   d_o2[p, c] = (disp[p] > 0 ? g[p] : 0) * w[c] * (o2[p, c] > 0)
+// final 1x1 conv to one channel + output activation (resample.hip dot_channels), input o2 is itself post-ReLU:
+//   gz[p] = g[p] * act'(.)      mode 0 (VDA head, ReLU):  disp > 0 ? g : 0
+//                               mode 1 / 2 (HeadDepth, sigmoid(+-z), dpt_pyramid.py:103-109):  +-g * disp * (1 - disp)
+//   d_o2[p, c] = gz[p] * w[c] * (o2[p, c] > 0);   gz_out (optional) keeps gz for the weight / bias gradient of the 1x1 conv
 __global__ __launch_bounds__(256) void dot_channels_bwd_kernel(const float *__restrict__ g, const float *__restrict__ disp, const float *__restrict__ w,
-                                                               const float *__restrict__ o2, float *__restrict__ d_o2, long long npix, int C) {
+                                                               const float *__restrict__ o2, float *__restrict__ d_o2, float *__restrict__ gz_out,
+                                                               long long npix, int C, int mode) {
     const int c4n = C >> 2;
     const long long total = npix * c4n;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
         const long long p = i / c4n;
         const int c = (int)(i - p * c4n) * 4;
-        const float gz = disp[p] > 0.f ? g[p] : 0.f;
+        const float dv = disp[p];
+        float gz;
+        if (mode == 0) {
+            gz = dv > 0.f ? g[p] : 0.f;
+        } else {
+            const float t = g[p] * (dv * (1.f - dv));
+            gz = mode == 1 ? t : -t;
+        }
+        if (gz_out && c == 0) gz_out[p] = gz;
         const f32x4 o = *reinterpret_cast<const f32x4 *>(o2 + i * 4);
         const f32x4 ww = *reinterpret_cast<const f32x4 *>(w + c);
         f32x4 d;
@@ -834,9 +845,11 @@ int bilinear_bwd(const float *dy, float *dx, int F, int ih, int iw, int C, int o
     return 0;
 }
 
-int dot_channels_bwd(const float *g, const float *disp, const float *w, const float *o2, float *d_o2, long long npix, int C, hipStream_t st) {
+int dot_channels_bwd(const float *g, const float *disp, const float *w, const float *o2, float *d_o2, float *gz_out, long long npix, int C, int mode,
+                     hipStream_t st) {
     EDV_CHECK(g && disp && w && o2 && d_o2 && npix > 0 && C % 4 == 0, "shape");
-    hipLaunchKernelGGL(dot_channels_bwd_kernel, dim3(ew_blocks(npix * (C / 4))), dim3(256), 0, st, g, disp, w, o2, d_o2, npix, C);
+    EDV_CHECK(mode >= 0 && mode <= 2, "mode: 0 ReLU, 1 sigmoid(z), 2 sigmoid(-z)");
+    hipLaunchKernelGGL(dot_channels_bwd_kernel, dim3(ew_blocks(npix * (C / 4))), dim3(256), 0, st, g, disp, w, o2, d_o2, gz_out, npix, C, mode);
     EDV_LAUNCH_OK();
     return 0;
 }

@@ -71,6 +71,7 @@ struct edv_ctx {
     bool have_saved = false;      // a training forward has run since the last backward
     bool grad_encoder = true;     // which factor gradients the caller wants (edv_set_grad_scope): the trainer alternates
     bool grad_temporal = true;    // spatial and temporal tuning phases (trainer_end_to_end_video.py:327-339)
+    bool grad_head = false;       // weight / bias gradients of the output-head convolutions (conv_depth_*, or scratch.output_conv* with --train_output_conv)
     std::unordered_map<std::string, Buf> grads;  // gradients of the trainable parameters, owned
     int launches = 0;
     size_t bytes = 0;
@@ -1033,12 +1034,15 @@ struct Run {
             const float *paths[4] = {p1, p2, p3, p4};
             const int hs[4] = {h0, h1, h2, h3}, wsz[4] = {w0, w1, w2, w3};
             const int Fh = Fe / 2;
-            float *o1, *up, *o2;
-            EDV_TRY(wsbuf("hd.o1", (size_t)F * h0 * w0 * Fh, &o1));
-            EDV_TRY(wsbuf("hd.up", (size_t)F * 4 * h0 * w0 * Fh, &up));
-            EDV_TRY(wsbuf("hd.o2", (size_t)F * 4 * h0 * w0 * 32, &o2));
             for (int k = 3; k >= 0; --k) {
                 const std::string hp = "head.conv_depth_" + std::to_string(k + 1) + ".head.";
+                // training keeps every head's intermediates (and its sigmoid output) for the backward; inference shares one scratch set
+                const std::string tg = c->train ? "hd" + std::to_string(k) + "." : "hd.";
+                const size_t px = (size_t)F * hs[k] * wsz[k], px0 = c->train ? px : (size_t)F * h0 * w0;
+                float *o1, *up, *o2;
+                EDV_TRY(wsbuf(tg + "o1", px0 * Fh, &o1));
+                EDV_TRY(wsbuf(tg + "up", px0 * 4 * Fh, &up));
+                EDV_TRY(wsbuf(tg + "o2", px0 * 4 * 32, &o2));
                 const float *w, *b;
                 EDV_TRY(packedw(hp + "0.weight", &w));
                 EDV_TRY(param(hp + "0.bias", &b));
@@ -1049,8 +1053,13 @@ struct Run {
                 EDV_TRY(conv3(up, 2 * hs[k], 2 * wsz[k], Fh, w, b, 32, 1, o2, false, ACT_RELU));
                 EDV_TRY(param(hp + "4.weight", &w));
                 EDV_TRY(param(hp + "4.bias", &b));
-                EDV_TRY(dot_channels(o2, w, b, disp[k], (long long)F * 4 * hs[k] * wsz[k], 32, cfg.inv_sigmoid ? ACT_SIGMOID_NEG : ACT_SIGMOID, st));
+                EDV_TRY(dot_channels(o2, w, b, disp[k], (long long)px * 4, 32, cfg.inv_sigmoid ? ACT_SIGMOID_NEG : ACT_SIGMOID, st));
                 c->launches += 2;
+                if (c->train) {
+                    float *dk;
+                    EDV_TRY(wsbuf(tg + "disp", px * 4, &dk));
+                    EDV_TRY(copy_f32(disp[k], dk, (long long)px * 4, st));
+                }
             }
         }
         return 0;
@@ -1095,8 +1104,7 @@ struct Run {
     int prepare_train() {
         EDV_CHECK(!cfg.use_bn, "the fine-tune step with use_bn=True is not built (train-mode BatchNorm uses batch statistics)");
         EDV_CHECK(c->prepared, "edv_prepare has not run");
-        EDV_CHECK(!cfg.conv_head && !cfg.use_clstoken && !cfg.residual_mask && !cfg.out_sigmoid,
-                  "training supports the VDA head without use_clstoken / residual blocks / out_sigmoid");
+        EDV_CHECK(!cfg.use_clstoken && !cfg.residual_mask && !cfg.out_sigmoid, "training does not support use_clstoken / residual blocks / out_sigmoid");
         EDV_CHECK(cfg.lora_type != EDV_LORA_DASH, "training supports lora_type none, lora, dvlora and ssb");
         const int *oc = cfg.out_channels;
         for (int i = 0; i < depth; ++i) {
@@ -1128,8 +1136,15 @@ struct Run {
             }
             EDV_TRY(make_t_lin(p + ".out_conv"));
         }
-        EDV_TRY(make_b_c3("head.scratch.output_conv1"));
-        EDV_TRY(make_b_c3("head.scratch.output_conv2.0"));
+        if (cfg.conv_head) {
+            for (int k = 1; k <= 4; ++k) {
+                EDV_TRY(make_b_c3("head.conv_depth_" + std::to_string(k) + ".head.0"));
+                EDV_TRY(make_b_c3("head.conv_depth_" + std::to_string(k) + ".head.2"));
+            }
+        } else {
+            EDV_TRY(make_b_c3("head.scratch.output_conv1"));
+            EDV_TRY(make_b_c3("head.scratch.output_conv2.0"));
+        }
         const int mmC[4] = {oc[2], oc[3], Fe, Fe};
         for (int m = 0; m < 4; ++m) {
             const std::string p = "head.motion_modules." + std::to_string(m) + ".temporal_transformer";
@@ -1156,10 +1171,38 @@ struct Run {
         EDV_TRY(packedw("T." + key, &wt));
         return linear(dY, M, N, wt, K, nullptr, dX, ACT_NONE, nullptr, R1);
     }
-    int dconv3(const float *dY, int H, int W, int Cout_fwd, const std::string &p, int Cin_fwd, float *dX) {
+    int dconv3(const float *dY, int H, int W, int Cout_fwd, const std::string &p, int Cin_fwd, float *dX, const float *add = nullptr) {
         const float *wb;
         EDV_TRY(packedw("B." + p, &wb));
-        return conv3(dY, H, W, Cout_fwd, wb, nullptr, Cin_fwd, 1, dX, false);
+        return conv3(dY, H, W, Cout_fwd, wb, nullptr, Cin_fwd, 1, dX, false, ACT_NONE, add);
+    }
+    // weight + bias gradient of a trainable 3x3 convolution p (x: its input, dY: the gradient of its output), when the caller asked for them
+    int conv_param_grads(const std::string &p, const float *x, const float *dY, int H, int W, int Cin, int Cout) {
+        if (!c->grad_head) return 0;
+        float *dw, *db, *ws;
+        EDV_TRY(gradbuf(p + ".weight", (size_t)Cout * Cin * 9, &dw));
+        EDV_TRY(gradbuf(p + ".bias", (size_t)Cout, &db));
+        size_t need = conv3_wgrad_workspace(F, H, W, Cin, Cout);
+        const size_t cs = colsum_workspace(Cout);
+        need = need > cs ? need : cs;
+        EDV_TRY(wsbuf("g.wgrad", need, &ws));
+        EDV_TRY(conv3_wgrad(x, dY, dw, F, H, W, Cin, Cout, ws, need, false, st));
+        EDV_TRY(colsum_rows(dY, nullptr, (long long)F * H * W, Cout, ws, need, db, false, st));
+        c->launches += 4;
+        return 0;
+    }
+    // weight + bias gradient of a 1x1 convolution to one channel: dW[c] = sum_p gz[p] o2[p, c], db = sum_p gz[p]
+    int dot_param_grads(const std::string &p, const float *o2, const float *gz, long long npix, int C) {
+        if (!c->grad_head) return 0;
+        float *dw, *db, *ws;
+        EDV_TRY(gradbuf(p + ".weight", (size_t)C, &dw));
+        EDV_TRY(gradbuf(p + ".bias", 1, &db));
+        const size_t need = colsum_workspace(C);
+        EDV_TRY(wsbuf("g.wgrad1", need, &ws));
+        EDV_TRY(colsum_rows(o2, gz, npix, C, ws, need, dw, false, st));
+        EDV_TRY(colsum_rows(gz, nullptr, npix, 1, ws, need, db, false, st));
+        c->launches += 4;
+        return 0;
     }
 
     // motion module backward, in place on d [F, P, C] (dL/d output -> dL/d input)
@@ -1275,34 +1318,73 @@ struct Run {
             lora_ws_n = need;
         }
 
-        // ---------------- output head: disp[k] = down(disp[k-1]); disp[0] = relu(dot(relu(conv2(up(conv1(p1)))))) ----
-        int sh[4], sw[4];
-        sh[0] = ih; sw[0] = iw;
-        for (int k = 1; k < 4; ++k) { sh[k] = sh[k - 1] / 2; sw[k] = sw[k - 1] / 2; }
-        float *gd[3];
-        for (int k = 2; k >= 0; --k) {
-            EDV_TRY(wsbuf("g.d" + std::to_string(k), (size_t)F * sh[k] * sw[k], &gd[k]));
-            EDV_TRY(copy_f32(g[k], gd[k], (long long)F * sh[k] * sw[k], st));
-            EDV_TRY(bilinear_bwd(k == 2 ? g[3] : gd[k + 1], gd[k], F, sh[k], sw[k], 1, sh[k + 1], sw[k + 1], true, st));
-        }
-        float *d_o2, *d_up, *d_o1, *d_p1;
-        const float *o2, *w;
-        EDV_TRY(saved("hd.o2", &o2));
-        EDV_TRY(wsbuf("g.o2", (size_t)F * ih * iw * 32, &d_o2));
-        EDV_TRY(wsbuf("g.up", (size_t)F * ih * iw * Fh, &d_up));
-        EDV_TRY(wsbuf("g.o1", (size_t)F * h0 * w0 * Fh, &d_o1));
+        float *d_p1, *d_p2, *d_p3, *d_p4, *d_r[5];
         EDV_TRY(wsbuf("g.p1", (size_t)F * h0 * w0 * Fe, &d_p1));
-        EDV_TRY(param("head.scratch.output_conv2.2.weight", &w));
-        EDV_TRY(dot_channels_bwd(gd[0], disp0, w, o2, d_o2, (long long)F * ih * iw, 32, st));
-        EDV_TRY(dconv3(d_o2, ih, iw, 32, "head.scratch.output_conv2.0", Fh, d_up));
-        EDV_TRY(bilinear_bwd(d_up, d_o1, F, h0, w0, Fh, ih, iw, false, st));
-        EDV_TRY(dconv3(d_o1, h0, w0, Fh, "head.scratch.output_conv1", Fe, d_p1));
-
-        // ---------------- fusion blocks and the two motion modules between them ----------------
-        float *d_p2, *d_p3, *d_p4, *d_r[5];
         EDV_TRY(wsbuf("g.p2", (size_t)F * h1 * w1 * Fe, &d_p2));
         EDV_TRY(wsbuf("g.p3", (size_t)F * h2 * w2 * Fe, &d_p3));
         EDV_TRY(wsbuf("g.p4", (size_t)F * h3 * w3 * Fe, &d_p4));
+        // HeadDepth k on path_(k+1) (endodav/layers.py:206-221, dpt_pyramid.py:103-109): gradient of the path, written to dst or added to it
+        auto head_depth_bwd = [&](int k, int h, int w, const std::string &path, float *dst, bool add) -> int {
+            const std::string hp = "head.conv_depth_" + std::to_string(k + 1) + ".head.", tg = "hd" + std::to_string(k) + ".";
+            const long long px = (long long)F * h * w;
+            const float *pk, *o1, *up, *o2, *dk, *w4;
+            EDV_TRY(saved(path, &pk));
+            EDV_TRY(saved(tg + "o1", &o1));
+            EDV_TRY(saved(tg + "up", &up));
+            EDV_TRY(saved(tg + "o2", &o2));
+            EDV_TRY(saved(tg + "disp", &dk));
+            (void)o1;
+            float *d_o2, *d_up, *d_o1, *gz;
+            EDV_TRY(wsbuf("g.o2", (size_t)F * 4 * h0 * w0 * 32, &d_o2));
+            EDV_TRY(wsbuf("g.up", (size_t)F * 4 * h0 * w0 * Fh, &d_up));
+            EDV_TRY(wsbuf("g.o1", (size_t)F * h0 * w0 * Fh, &d_o1));
+            EDV_TRY(wsbuf("g.gz", (size_t)F * 4 * h0 * w0, &gz));
+            EDV_TRY(param(hp + "4.weight", &w4));
+            EDV_TRY(dot_channels_bwd(g[k], dk, w4, o2, d_o2, gz, px * 4, 32, cfg.inv_sigmoid ? 2 : 1, st));
+            EDV_TRY(dot_param_grads(hp + "4", o2, gz, px * 4, 32));
+            EDV_TRY(conv_param_grads(hp + "2", up, d_o2, 2 * h, 2 * w, Fh, 32));
+            EDV_TRY(dconv3(d_o2, 2 * h, 2 * w, 32, hp + "2", Fh, d_up));
+            EDV_TRY(bilinear_bwd(d_up, d_o1, F, h, w, Fh, 2 * h, 2 * w, false, st));
+            EDV_TRY(conv_param_grads(hp + "0", pk, d_o1, h, w, Fe, Fh));
+            EDV_TRY(dconv3(d_o1, h, w, Fh, hp + "0", Fe, dst, add ? dst : nullptr));
+            c->launches += 2;
+            return 0;
+        };
+        if (cfg.conv_head) {
+            EDV_TRY(head_depth_bwd(0, h0, w0, "p1", d_p1, false));
+        } else {
+            // ---------------- VDA head: disp[k] = down(disp[k-1]); disp[0] = relu(dot(relu(conv2(up(conv1(p1)))))) ----
+            int sh[4], sw[4];
+            sh[0] = ih; sw[0] = iw;
+            for (int k = 1; k < 4; ++k) { sh[k] = sh[k - 1] / 2; sw[k] = sw[k - 1] / 2; }
+            float *gd[3];
+            for (int k = 2; k >= 0; --k) {
+                EDV_TRY(wsbuf("g.d" + std::to_string(k), (size_t)F * sh[k] * sw[k], &gd[k]));
+                EDV_TRY(copy_f32(g[k], gd[k], (long long)F * sh[k] * sw[k], st));
+                EDV_TRY(bilinear_bwd(k == 2 ? g[3] : gd[k + 1], gd[k], F, sh[k], sw[k], 1, sh[k + 1], sw[k + 1], true, st));
+            }
+            float *d_o2, *d_up, *d_o1, *gz = nullptr;
+            const float *o2, *w, *p1, *up;
+            EDV_TRY(saved("hd.o2", &o2));
+            EDV_TRY(wsbuf("g.o2", (size_t)F * ih * iw * 32, &d_o2));
+            EDV_TRY(wsbuf("g.up", (size_t)F * ih * iw * Fh, &d_up));
+            EDV_TRY(wsbuf("g.o1", (size_t)F * h0 * w0 * Fh, &d_o1));
+            if (c->grad_head) EDV_TRY(wsbuf("g.gz", (size_t)F * ih * iw, &gz));  // --train_output_conv (endodav/layers.py:5-34)
+            EDV_TRY(param("head.scratch.output_conv2.2.weight", &w));
+            EDV_TRY(dot_channels_bwd(gd[0], disp0, w, o2, d_o2, gz, (long long)F * ih * iw, 32, 0, st));
+            if (c->grad_head) {
+                EDV_TRY(saved("hd.up", &up));
+                EDV_TRY(saved("p1", &p1));
+                EDV_TRY(dot_param_grads("head.scratch.output_conv2.2", o2, gz, (long long)F * ih * iw, 32));
+                EDV_TRY(conv_param_grads("head.scratch.output_conv2.0", up, d_o2, ih, iw, Fh, 32));
+            }
+            EDV_TRY(dconv3(d_o2, ih, iw, 32, "head.scratch.output_conv2.0", Fh, d_up));
+            EDV_TRY(bilinear_bwd(d_up, d_o1, F, h0, w0, Fh, ih, iw, false, st));
+            if (c->grad_head) EDV_TRY(conv_param_grads("head.scratch.output_conv1", p1, d_o1, h0, w0, Fe, Fh));
+            EDV_TRY(dconv3(d_o1, h0, w0, Fh, "head.scratch.output_conv1", Fe, d_p1));
+        }
+
+        // ---------------- fusion blocks and the two motion modules between them ----------------
         EDV_TRY(wsbuf("g.r1", (size_t)F * h1 * w1 * Fe, &d_r[1]));
         EDV_TRY(wsbuf("g.r2", (size_t)F * h2 * w2 * Fe, &d_r[2]));
         EDV_TRY(wsbuf("g.r3", (size_t)F * h3 * w3 * Fe, &d_r[3]));
@@ -1310,9 +1392,12 @@ struct Run {
         const float *r[5];
         for (int j = 1; j <= 4; ++j) EDV_TRY(saved("r" + std::to_string(j), &r[j]));
         EDV_TRY(fusion_bwd(1, d_p1, nullptr, r[1], h1, w1, h0, w0, d_p2, d_r[1]));
+        if (cfg.conv_head) EDV_TRY(head_depth_bwd(1, h1, w1, "p2", d_p2, true));   // path_2 also feeds conv_depth_2
         EDV_TRY(fusion_bwd(2, d_p2, nullptr, r[2], h2, w2, h1, w1, d_p3, d_r[2]));
+        if (cfg.conv_head) EDV_TRY(head_depth_bwd(2, h2, w2, "p3", d_p3, true));   // path_3 (after motion module 3) feeds conv_depth_3
         EDV_TRY(motion_module_bwd(3, d_p3, h2 * w2, Fe));
         EDV_TRY(fusion_bwd(3, d_p3, nullptr, r[3], h3, w3, h2, w2, d_p4, d_r[3]));
+        if (cfg.conv_head) EDV_TRY(head_depth_bwd(3, h3, w3, "p4", d_p4, true));
         EDV_TRY(motion_module_bwd(2, d_p4, h3 * w3, Fe));
         EDV_TRY(fusion_bwd(4, d_p4, r[4], nullptr, h4, w4, h3, w3, d_r[4], nullptr));
 
@@ -1559,8 +1644,7 @@ int edv_forward(edv_ctx *ctx, const float *x_dev, int32_t B, int32_t T, int32_t 
     for (int k = 0; k < 4; ++k) EDV_CHECK(disp_dev[k], "null output");
     if (ctx->train) {
         const edv_config &c = ctx->cfg;
-        EDV_CHECK(!c.conv_head && !c.use_clstoken && !c.residual_mask && !c.out_sigmoid,
-                  "training supports the VDA head without use_clstoken / residual blocks / out_sigmoid");
+        EDV_CHECK(!c.use_clstoken && !c.residual_mask && !c.out_sigmoid, "training does not support use_clstoken / residual blocks / out_sigmoid");
         EDV_CHECK(c.lora_type != EDV_LORA_DASH, "training supports lora_type none, lora, dvlora and ssb");
         EDV_CHECK(!ctx->capture, "stage capture and training are exclusive");
     }
@@ -1584,10 +1668,11 @@ int edv_set_encoder_streams(edv_ctx *ctx, int32_t n) {
     return 0;
 }
 
-int edv_set_grad_scope(edv_ctx *ctx, int32_t encoder_factors, int32_t temporal_factors) {
+int edv_set_grad_scope(edv_ctx *ctx, int32_t encoder_factors, int32_t temporal_factors, int32_t head_convs) {
     EDV_CHECK(ctx, "null context");
     ctx->grad_encoder = encoder_factors != 0;
     ctx->grad_temporal = temporal_factors != 0;
+    ctx->grad_head = head_convs != 0;
     return 0;
 }
 

@@ -143,7 +143,16 @@ int lora_grads(const float *X, int ldx, const float *G, int ldg, long long M, in
 int ssb_prep(const float *W, const float *a, const float *b, const float *gamma, float *Wa, float *gb, int nout, int nin, hipStream_t st);
 int col_dot(const float *P, const float *Q, long long M, int N, const float *scale, float *part, float *out, hipStream_t st);
 int bilinear_bwd(const float *dy, float *dx, int F, int ih, int iw, int C, int oh, int ow, bool accumulate, hipStream_t st);
-int dot_channels_bwd(const float *g, const float *disp, const float *w, const float *o2, float *d_o2, long long npix, int C, hipStream_t st);
+// 1x1 conv to one channel + output activation: mode 0 ReLU (VDA head), 1 sigmoid(z), 2 sigmoid(-z) (HeadDepth); gz_out (optional) = dL/dz
+int dot_channels_bwd(const float *g, const float *disp, const float *w, const float *o2, float *d_o2, float *gz_out, long long npix, int C, int mode,
+                     hipStream_t st);
+// weight gradient of a 3x3 / stride 1 / padding 1 convolution (wgrad.hip): x [F,H,W,Cin], dy [F,H,W,Cout] -> dw [Cout,Cin,3,3] (torch layout)
+size_t conv3_wgrad_workspace(int F, int H, int W, int Cin, int Cout);  // floats
+int conv3_wgrad(const float *x, const float *dy, float *dw, int F, int H, int W, int Cin, int Cout, float *ws, size_t ws_floats, bool accumulate,
+                hipStream_t st);
+// out[n] (+)= sum_m rowscale[m] * P[m, n]  (rowscale may be null; N a power of two in 4..1024, or 1): bias gradients, 1x1-conv weight gradient
+size_t colsum_workspace(int N);  // floats
+int colsum_rows(const float *P, const float *rowscale, long long M, int N, float *ws, size_t ws_floats, float *out, bool accumulate, hipStream_t st);
 int groupnorm_bwd(const float *x, const float *stats, const float *w, const float *dy, float *sums, float *dx, int F, int P, int C, int groups, bool accumulate,
                   hipStream_t st);
 int attn_temporal_bwd(const float *qkv, const float *dout, float *dqkv, int B, int T, int P, int C, int heads, hipStream_t st);

@@ -346,6 +346,12 @@ def _is_lora_factor(name: str) -> bool:
     return (".mlp.fc" in name or ".ff.net.2." in name) and name.rsplit(".", 1)[-1] in ("lora_A", "lora_B", "lora_U", "lora_V")
 
 
+def _is_head_conv(name: str) -> bool:
+    """Weights / biases of the output-head convolutions the HIP backward differentiates: the HeadDepth heads (trainable by default,
+    endodav/layers.py:5-34) and, for the VDA head, scratch.output_conv* (--train_output_conv)."""
+    return (name.startswith("head.conv_depth_") or name.startswith("head.scratch.output_conv")) and name.rsplit(".", 1)[-1] in ("weight", "bias")
+
+
 class _NativeCtx:
     """Owns one ``edv_ctx`` (one device).  Destroyed with the last module/replica that references it."""
 
@@ -385,7 +391,8 @@ class _EdvFunction(torch.autograd.Function):
             stream = C.c_void_p(_lib.stream_ptr(ctx.device))
             enc = any(".mlp.fc" in n for n in ctx.names)
             tmp = any(".ff.net.2." in n for n in ctx.names)
-            _lib.check(lib.edv_set_grad_scope(C.c_void_p(ctx.handle), int(enc), int(tmp)), "edv_set_grad_scope")
+            hd = any(_is_head_conv(n) for n in ctx.names)
+            _lib.check(lib.edv_set_grad_scope(C.c_void_p(ctx.handle), int(enc), int(tmp), int(hd)), "edv_set_grad_scope")
             _lib.check(lib.edv_backward(C.c_void_p(ctx.handle), disp0.data_ptr(), ptrs, stream), "edv_backward")
             grads = []
             for name, shp in zip(ctx.names, ctx.param_shapes):
@@ -609,12 +616,12 @@ class endodav(nn.Module):
         gradients of the LoRA factors of mlp.fc1 / mlp.fc2 (what ``mark_only_part_as_trainable`` leaves trainable for
         lora / dvlora, endodav/layers.py:5-34); a trainable parameter outside that set is refused, not silently frozen."""
         names = [n for n, p in self.state_dict(keep_vars=True).items() if p.requires_grad]
-        bad = [n for n in names if not ((".mlp.fc" in n or ".ff.net.2." in n) and n.rsplit(".", 1)[-1] in ("lora_A", "lora_B", "lora_U", "lora_V"))]
+        bad = [n for n in names if not (_is_lora_factor(n) or _is_head_conv(n))]
         if bad:
-            raise NotImplementedError(f"libendodav_hip has no gradient for {bad[:4]}{' ...' if len(bad) > 4 else ''}: only the LoRA factors of the "
-                                      "encoder MLPs (and, with temporal_lora, of ff.net.2 in the motion modules) are trainable through the HIP "
-                                      "backward (SURVEY.md §8f rank 3)")
-        if names and self.lora_type not in ("lora", "dvlora", "ssb"):
+            raise NotImplementedError(f"libendodav_hip has no gradient for {bad[:4]}{' ...' if len(bad) > 4 else ''}: the HIP backward covers the LoRA "
+                                      "factors of the encoder MLPs (and, with temporal_lora, of ff.net.2 in the motion modules) and the output-head "
+                                      "convolutions conv_depth_* / scratch.output_conv* (SURVEY.md §8f rank 3)")
+        if any(_is_lora_factor(n) for n in names) and self.lora_type not in ("lora", "dvlora", "ssb"):
             raise NotImplementedError(f"the HIP backward supports lora_type 'lora', 'dvlora' and 'ssb', not {self.lora_type!r}")
         return names
 

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EDV_ABI_VERSION 4
+#define EDV_ABI_VERSION 5
 
 enum edv_lora_type { EDV_LORA_NONE = 0, EDV_LORA_LORA = 1, EDV_LORA_DVLORA = 2, EDV_LORA_SSB = 3, EDV_LORA_DASH = 4 };
 
@@ -233,10 +233,13 @@ int edv_fold_lora(const float *W_dev, const float *A_dev, const float *B_dev, co
  * ("head.motion_modules.<m>...ff.net.2.lora_*") -- the trainable set of endodav/layers.py:5-34 -- in context-owned
  * device memory, fetched with edv_grad(ctx, name, &ptr, &numel).  edv_prepare must run again after the optimizer step. */
 int edv_set_train(edv_ctx *ctx, int32_t on);
-/* Which factor gradients the next edv_backward has to produce.  The trainer alternates spatial and temporal tuning phases
+/* Which gradients the next edv_backward has to produce.  The trainer alternates spatial and temporal tuning phases
  * (trainer_end_to_end_video.py:327-339); with encoder_factors = 0 the backward stops at the head (nothing below it is
- * trainable), with temporal_factors = 0 the ff.net.2 products are skipped.  Default: both. */
-int edv_set_grad_scope(edv_ctx *ctx, int32_t encoder_factors, int32_t temporal_factors);
+ * trainable), with temporal_factors = 0 the ff.net.2 products are skipped.  head_convs != 0 adds the weight and bias gradients of
+ * the output-head convolutions, named like the state_dict: "head.conv_depth_<k>.head.{0,2,4}.{weight,bias}" with the conv head
+ * (trainable by default, endodav/layers.py:5-34), "head.scratch.output_conv1.*", "head.scratch.output_conv2.{0,2}.*" with the VDA
+ * head (--train_output_conv).  Default: both factor sets, no head convolutions. */
+int edv_set_grad_scope(edv_ctx *ctx, int32_t encoder_factors, int32_t temporal_factors, int32_t head_convs);
 int edv_backward(edv_ctx *ctx, const float *disp0_dev, const float *const grad_disp_dev[4], void *stream);
 int edv_grad(edv_ctx *ctx, const char *name, float **grad_dev, int64_t *numel);
 int edv_grad_copy(edv_ctx *ctx, const char *name, float *dst_dev, int64_t numel, void *stream); /* stream-ordered copy into caller memory */
@@ -262,9 +265,21 @@ int edv_lora_grads(const float *x_dev, const float *g_dev, int64_t M, int32_t ni
 /* bilinear align_corners=True, input gradient: dy [F,oh,ow,C] -> dx [F,ih,iw,C] (deterministic gather). */
 int edv_bilinear_bwd(const float *dy_dev, float *dx_dev, int32_t F, int32_t ih, int32_t iw, int32_t C, int32_t oh, int32_t ow, int32_t accumulate,
                      void *stream);
-/* final 1x1 conv to one channel + ReLU on a post-ReLU input: d_o2[p,c] = (disp[p] > 0 ? g[p] : 0) * w[c] * (o2[p,c] > 0). */
-int edv_dot_channels_bwd(const float *g_dev, const float *disp_dev, const float *w_dev, const float *o2_dev, float *d_o2_dev, int64_t npix, int32_t C,
-                         void *stream);
+/* final 1x1 conv to one channel + output activation on a post-ReLU input (dpt.py:121-123; endodav/layers.py:206-221 with the sigmoid
+ * of dpt_pyramid.py:103-109):  gz[p] = dL/dz;  mode 0 (ReLU): disp > 0 ? g : 0;  mode 1 / 2 (sigmoid(z) / sigmoid(-z)): +-g disp (1 - disp);
+ * d_o2[p,c] = gz[p] * w[c] * (o2[p,c] > 0).  gz_out_dev (optional, [npix]) keeps gz for the 1x1 conv's own weight / bias gradient. */
+int edv_dot_channels_bwd(const float *g_dev, const float *disp_dev, const float *w_dev, const float *o2_dev, float *d_o2_dev, float *gz_out_dev,
+                         int64_t npix, int32_t C, int32_t mode, void *stream);
+/* Weight gradient of a 3x3 / stride 1 / padding 1 convolution (the trainable convolutions of the output heads, endodav/layers.py:5-34):
+ * x [F,H,W,Cin] channels-last, dy [F,H,W,Cout] -> dw [Cout,Cin,3,3] (torch layout).   Deterministic (two stages). */
+size_t edv_conv3x3_wgrad_workspace(int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t Cout); /* bytes */
+int edv_conv3x3_wgrad(const float *x_dev, const float *dy_dev, float *dw_dev, int32_t F, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                      float *workspace_dev, size_t workspace_bytes, int32_t accumulate, void *stream);
+/* out[n] (+)= sum_m rowscale[m] * P[m,n] (rowscale may be NULL): bias gradients, and the 1x1 head's weight gradient with rowscale = gz.
+ * N a power of two in 4..1024, or 1 (then M % 4 == 0 and no rowscale). */
+size_t edv_colsum_workspace(int32_t N); /* bytes */
+int edv_colsum_rows(const float *P_dev, const float *rowscale_dev, int64_t M, int32_t N, float *workspace_dev, size_t workspace_bytes, float *out_dev,
+                    int32_t accumulate, void *stream);
 /* GroupNorm input gradient; stats = the forward's [F, groups, 2] (mean, rstd); sums = [F, groups, 2] scratch. */
 int edv_groupnorm_bwd(const float *x_dev, const float *stats_dev, const float *w_dev, const float *dy_dev, float *sums_dev, float *dx_dev, int32_t F,
                       int32_t P, int32_t C, int32_t groups, int32_t accumulate, void *stream);

@@ -83,6 +83,34 @@ def test_lora_gradients_match_oracle_autograd(lib, cuda, case):
     print(f"\n[{case}] {len(names)} tensors, worst scale-relative gradient error {worst:.2e}")
 
 
+@pytest.mark.parametrize("case,head_key", [("micro_conv_dvlora", "head.conv_depth_"), ("micro_conv_invsig_ssb", "head.conv_depth_"),
+                                           ("micro_vda_dvlora", "head.scratch.output_conv")],
+                         ids=["conv_head", "conv_head_inv_sigmoid_ssb", "vda_train_output_conv"])
+def test_output_head_conv_gradients(lib, cuda, case, head_key):
+    """The reference's default options leave the four HeadDepth heads trainable next to the LoRA factors (endodav/layers.py:5-34:
+    names containing conv_depth_), and --train_output_conv does the same for scratch.output_conv* of the VDA head: weight and bias
+    gradients of those convolutions (conv3_wgrad / colsum_rows) and the LoRA gradients that now collect from all four paths."""
+    model, kwargs, shape, kind, _ = build_model(case)
+    x = case_input(case)
+    names = []
+    for n, p in model.named_parameters():
+        p.requires_grad = ((".mlp.fc" in n and n.rsplit(".", 1)[-1] in ("lora_A", "lora_B")) or n.startswith(head_key))
+        if p.requires_grad:
+            names.append(n)
+    n_head = sum(n.startswith(head_key) for n in names)
+    assert n_head == (24 if "conv_depth" in head_key else 6), names
+    model = model.to(cuda).train()
+    BT = shape[0] * shape[1]
+    gouts = upstream([(BT, 1, h, w) for (h, w) in model.output_shapes()])
+    ref, out_ref = oracle_grads(model, kwargs, x, names, gouts)
+    hip, out = hip_grads(model, x, names, gouts, cuda)
+    for s in range(4):
+        a, b = out[("disp", s)].detach().cpu(), out_ref[("disp", s)].detach()
+        assert (a - b).abs().max().item() <= 5e-5 * b.abs().max().item()
+    worst = check(hip, ref)
+    print(f"\n[{case}] {len(names)} tensors ({n_head} head convolution tensors), worst scale-relative gradient error {worst:.2e}")
+
+
 @pytest.mark.parametrize("temporal", [False, True], ids=["spatial", "spatial+temporal"])
 def test_ssb_gradients(lib, cuda, temporal):
     """Linear_SSB (lora_A [in,1], lora_B [out,1]), the lora_type of the reference's scripts/train_video.sh, with and without

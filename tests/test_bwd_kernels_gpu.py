@@ -201,9 +201,62 @@ def test_dot_channels_bwd(lib, cuda):
     o2 = F.relu(o2pre)
     disp = F.relu(o2 @ w + b)
     d = torch.empty(npix, Cc, device=cuda)
-    _lib.check(lib.edv_dot_channels_bwd(keep(g.to(cuda)), keep(disp.to(cuda)), keep(w.to(cuda)), keep(o2.to(cuda)), d.data_ptr(), npix, Cc,
+    _lib.check(lib.edv_dot_channels_bwd(keep(g.to(cuda)), keep(disp.to(cuda)), keep(w.to(cuda)), keep(o2.to(cuda)), d.data_ptr(), None, npix, Cc, 0,
                                         st()))
     close(d, ref, 2e-6, "dot_channels_bwd")
+
+
+@pytest.mark.parametrize("neg", [False, True], ids=["sigmoid", "inv_sigmoid"])
+def test_dot_channels_bwd_sigmoid_head(lib, cuda, neg):
+    """HeadDepth's last two layers + the sigmoid of dpt_pyramid.py:103-109: input gradient, and the 1x1 conv's own weight / bias
+    gradient through colsum_rows with the kept dL/dz as the row scale."""
+    npix, Cc = 6000, 32
+    o2pre, w, b, g = rnd(npix, Cc, seed=1), rnd(Cc, seed=2), rnd(1, seed=4, scale=0.1), rnd(npix, seed=3)
+    sign = -1.0 if neg else 1.0
+    fwd = lambda z, ww, bb: torch.sigmoid(sign * (F.relu(z) @ ww + bb))
+    ref_z, ref_w, ref_b = grad_of(fwd, [o2pre, w, b], g)
+    o2 = F.relu(o2pre)
+    disp = fwd(o2pre, w, b)
+    d, gz = torch.empty(npix, Cc, device=cuda), torch.empty(npix, device=cuda)
+    o2d = o2.to(cuda)
+    _lib.check(lib.edv_dot_channels_bwd(keep(g.to(cuda)), keep(disp.to(cuda)), keep(w.to(cuda)), o2d.data_ptr(), d.data_ptr(), gz.data_ptr(), npix, Cc,
+                                        2 if neg else 1, st()))
+    close(d, ref_z, 2e-6, "dot_channels_bwd sigmoid")
+    nb = lib.edv_colsum_workspace(Cc)
+    ws = torch.empty(nb // 4, device=cuda)
+    dw, db = torch.full((Cc,), float("nan"), device=cuda), torch.full((1,), float("nan"), device=cuda)
+    _lib.check(lib.edv_colsum_rows(o2d.data_ptr(), gz.data_ptr(), npix, Cc, ws.data_ptr(), nb, dw.data_ptr(), 0, st()))
+    _lib.check(lib.edv_colsum_rows(gz.data_ptr(), None, npix, 1, ws.data_ptr(), nb, db.data_ptr(), 0, st()))
+    close(dw, ref_w, 3e-6, "1x1 weight gradient")
+    close(db, ref_b, 3e-6, "1x1 bias gradient")
+
+
+@pytest.mark.parametrize("M,N,acc", [(100000, 32, False), (777 * 4, 64, True), (1369 * 8, 128, False), (5, 4, False), (8 * 518 * 518, 32, False)])
+def test_colsum_rows(lib, cuda, M, N, acc):
+    P = rnd(M, N, seed=1) + 0.3
+    base = rnd(N, seed=2)
+    nb = lib.edv_colsum_workspace(N)
+    ws = torch.empty(nb // 4, device=cuda)
+    out = base.to(cuda) if acc else torch.full((N,), float("nan"), device=cuda)
+    _lib.check(lib.edv_colsum_rows(keep(P.to(cuda)), None, M, N, ws.data_ptr(), nb, out.data_ptr(), int(acc), st()))
+    close(out, P.double().sum(0) + (base.double() if acc else 0), 3e-6, "colsum_rows")
+
+
+@pytest.mark.parametrize("Fr,H,W,Cin,Cout,acc", [(2, 9, 12, 32, 32, False), (1, 37, 37, 64, 32, False), (3, 20, 26, 32, 32, True), (1, 7, 5, 128, 64, False),
+                                                 (2, 74, 74, 64, 32, False), (8, 148, 148, 32, 32, False), (1, 16, 16, 256, 128, False),
+                                                 (2, 12, 16, 16, 32, False), (1, 6, 8, 48, 20, True), (2, 11, 7, 4, 8, False)])
+def test_conv3x3_wgrad(lib, cuda, Fr, H, W, Cin, Cout, acc):
+    """dW of a 3x3 / stride 1 / padding 1 convolution (the HeadDepth / output_conv layers) against autograd in fp64."""
+    x, wt, g = rnd(Fr, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=0.1), rnd(Fr, Cout, H, W, seed=3)
+    (ref,) = grad_of(lambda ww: F.conv2d(x.double(), ww, padding=1), [wt], g)
+    base = rnd(Cout, Cin, 3, 3, seed=4)
+    xd, gd = x.permute(0, 2, 3, 1).contiguous().to(cuda), g.permute(0, 2, 3, 1).contiguous().to(cuda)
+    nb = lib.edv_conv3x3_wgrad_workspace(Fr, H, W, Cin, Cout)
+    assert nb > 0
+    ws = torch.full((nb // 4,), float("nan"), device=cuda)
+    dw = base.to(cuda) if acc else torch.full((Cout, Cin, 3, 3), float("nan"), device=cuda)
+    _lib.check(lib.edv_conv3x3_wgrad(xd.data_ptr(), gd.data_ptr(), dw.data_ptr(), Fr, H, W, Cin, Cout, ws.data_ptr(), nb, int(acc), st()), "edv_conv3x3_wgrad")
+    close(dw, ref + (base.double() if acc else 0), 5e-6, "conv3x3_wgrad")
 
 
 @pytest.mark.parametrize("Fr,P,Cc,acc", [(3, 37 * 37, 192, False), (2, 100, 64, True), (1, 9, 384, False)])

@@ -254,10 +254,10 @@ def test_errors_are_loud(cuda):
             model(torch.rand(1, 33, 3, 42, 56, device=cuda))
     with pytest.raises(KeyError):
         endodav_amd.endodav(encoder="vitx")
-    model.get_parameter("head.scratch.output_conv1.weight").requires_grad = True
+    model.get_parameter("head.scratch.layer1_rn.weight").requires_grad = True
     with pytest.raises(NotImplementedError):  # a trainable tensor the HIP backward has no gradient for is refused, not silently frozen
         model(x)
-    model.get_parameter("head.scratch.output_conv1.weight").requires_grad = False
+    model.get_parameter("head.scratch.layer1_rn.weight").requires_grad = False
     bn, _, xb, _ = run_hip("micro_bn", cuda)  # BatchNorm is folded from its running statistics: eval() only
     with pytest.raises(NotImplementedError, match="eval"):
         with torch.no_grad():

@@ -64,17 +64,24 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(const float *__restric
             row_ok[j] = col_ok[j] && yy >= 0 && yy < H;
             xr[j] = x + (((long long)f * H + (row_ok[j] ? yy : y)) * W) * Cin + ci0[j];
         }
-#pragma unroll 4
-        for (int xs = 0; xs < W; xs += 2) {
-            const int px = xs + lh;  // this lane-half's pixel of the pair
-            const float a = (px < W && co_ok) ? dyr[(long long)px * Cout] : 0.f;
+        // four pixel pairs per trip, every load of the trip issued before its first MFMA (the compiler does not unroll this loop itself)
+        for (int xs = 0; xs < W; xs += 8) {
+            float a[4], b[4][WG_NB];
 #pragma unroll
-            for (int j = 0; j < WG_NB; ++j) {
-                const int xx = px + dxo[j];
-                const bool ok = row_ok[j] && px < W && xx >= 0 && xx < W;
-                const float b = ok ? xr[j][(long long)xx * Cin] : 0.f;
-                acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[j], 0, 0, 0);
+            for (int u = 0; u < 4; ++u) {
+                const int px = xs + 2 * u + lh;  // this lane-half's pixel of pair u
+                a[u] = (px < W && co_ok) ? dyr[(long long)px * Cout] : 0.f;
+#pragma unroll
+                for (int j = 0; j < WG_NB; ++j) {
+                    const int xx = px + dxo[j];
+                    const bool ok = row_ok[j] && px < W && xx >= 0 && xx < W;
+                    b[u][j] = ok ? xr[j][(long long)xx * Cin] : 0.f;
+                }
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < WG_NB; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[u][j], acc[j], 0, 0, 0);
         }
     }
     float *dst = part + task * (WG_NB * 1024);
@@ -84,25 +91,41 @@ __global__ __launch_bounds__(256) void conv3_wgrad_kernel(const float *__restric
         for (int r = 0; r < 16; ++r) dst[j * 1024 + r * 64 + lane] = acc[j][r];
 }
 
-// dW[co, ci, ky, kx] (+)= sum over row chunks, in chunk order
+// dW[co, ci, ky, kx] (+)= sum over row chunks.  A block = 32 consecutive (co, column) elements x 8 slices of the chunk range; each
+// thread adds its slice in chunk order, the slices are added in slice order: a fixed order, hence deterministic.
 __global__ __launch_bounds__(256) void conv3_wgrad_reduce_kernel(const float *__restrict__ part, float *__restrict__ dw, int Cin, int Cout, int n_rc, int n_cg,
                                                                  int accumulate) {
-    const int i = blockIdx.x * 256 + threadIdx.x;  // one thread per (co, column): column = tap * Cin + ci
+    __shared__ float red[8][32];
+    const int e = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + e;  // (co, column): column = tap * Cin + ci
     const int K9 = 9 * Cin;
-    if (i >= Cout * K9) return;
-    const int co = i / K9, col = i - co * K9;
-    const int cb = co >> 5, m = co & 31;
-    const int b = col >> 5, n = col & 31;
-    const int cg = b / WG_NB, j = b - cg * WG_NB;
-    // accumulator element (m, n) of a 32x32 block: register r of lane (n, h) holds row (r & 3) + 8 (r >> 2) + 4 h
-    const int h = (m >> 2) & 1, r = (m & 3) + 4 * (m >> 3);
-    const long long t0 = ((long long)cb * n_cg + cg) * n_rc;
-    const float *p = part + t0 * (WG_NB * 1024) + j * 1024 + r * 64 + h * 32 + n;
+    const bool live = i < Cout * K9;
     float s = 0.f;
-    for (int rc = 0; rc < n_rc; ++rc) s += p[(long long)rc * (WG_NB * 1024)];
-    const int tap = col / Cin, ci = col - tap * Cin;
-    float *o = dw + ((long long)co * Cin + ci) * 9 + tap;
-    *o = accumulate ? *o + s : s;
+    int co = 0, col = 0;
+    if (live) {
+        co = i / K9;
+        col = i - co * K9;
+        const int cb = co >> 5, m = co & 31;
+        const int b = col >> 5, n = col & 31;
+        const int cg = b / WG_NB, j = b - cg * WG_NB;
+        // accumulator element (m, n) of a 32x32 block: register r of lane (n, h) holds row (r & 3) + 8 (r >> 2) + 4 h
+        const int h = (m >> 2) & 1, r = (m & 3) + 4 * (m >> 3);
+        const long long t0 = ((long long)cb * n_cg + cg) * n_rc;
+        const float *p = part + t0 * (WG_NB * 1024) + j * 1024 + r * 64 + h * 32 + n;
+        const int per = (n_rc + 7) / 8, rc0 = slice * per, rc1 = rc0 + per < n_rc ? rc0 + per : n_rc;
+#pragma unroll 8
+        for (int rc = rc0; rc < rc1; ++rc) s += p[(long long)rc * (WG_NB * 1024)];
+    }
+    red[slice][e] = s;
+    __syncthreads();
+    if (slice == 0 && live) {
+        float t = red[0][e];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][e];
+        const int tap = col / Cin, ci = col - tap * Cin;
+        float *o = dw + ((long long)co * Cin + ci) * 9 + tap;
+        *o = accumulate ? *o + t : t;
+    }
 }
 
 // part[block, n] = sum over the block's share of rows of rowscale[m] * P[m, n]; P is walked as a flat array of float4 with a
@@ -126,27 +149,37 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float *__rest
     }
 }
 
-// out[n] (+)= sum over blocks of part[block, n] in block order; fold != 0 adds the N columns into out[0] (a [M,1] input viewed as [M/4,4])
+// out[n] (+)= sum over blocks of part[block, n]: 32 columns x 8 slices of the block range per workgroup, fixed order.  fold != 0 adds the
+// N columns into out[0] (a [M,1] input viewed as [M/4,4]; then N = 4 and there is one workgroup).
 __global__ __launch_bounds__(256) void colsum_reduce_kernel(const float *__restrict__ part, int blocks, int N, int fold, int accumulate, float *__restrict__ out) {
-    __shared__ float sh[256];
-    const int n = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float red[8][32];
+    const int e = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + e;
     float s = 0.f;
-    if (n < N)
-        for (int b = 0; b < blocks; ++b) s += part[(long long)b * N + n];
+    if (n < N) {
+        const int per = (blocks + 7) / 8, b0 = slice * per, b1 = b0 + per < blocks ? b0 + per : blocks;
+#pragma unroll 8
+        for (int b = b0; b < b1; ++b) s += part[(long long)b * N + n];
+    }
+    red[slice][e] = s;
+    __syncthreads();
+    if (slice != 0 || n >= N) return;
+    float t = red[0][e];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) t += red[k][e];
     if (!fold) {
-        if (n < N) out[n] = accumulate ? out[n] + s : s;
+        out[n] = accumulate ? out[n] + t : t;
         return;
     }
-    sh[threadIdx.x] = n < N ? s : 0.f;  // fold: N <= 256, one block
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float t = 0.f;
-        for (int k = 0; k < N; ++k) t += sh[k];
-        out[0] = accumulate ? out[0] + t : t;
+    red[0][e] = t;  // fold: lanes 0..3 of one wave hold the four sums
+    __builtin_amdgcn_wave_barrier();
+    if (e == 0) {
+        const float f = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        out[0] = accumulate ? out[0] + f : f;
     }
 }
 
-constexpr int COLSUM_BLOCKS = 1024;
+constexpr int COLSUM_BLOCKS = 512;
 
 }  // namespace
 
@@ -154,8 +187,8 @@ static void wgrad_plan(int F, int H, int Cin, int Cout, int *rows_per_task, int 
     *n_cg = ((9 * Cin + 31) / 32 + WG_NB - 1) / WG_NB;
     *n_cb = (Cout + 31) / 32;
     const long long rows = (long long)F * H;
-    // ~8 waves per SIMD of work in flight (1024 SIMDs), at least one image row per wave
-    long long want = 8192 / ((long long)*n_cg * *n_cb);
+    // ~4 waves per SIMD of work (1024 SIMDs), at least one image row per wave; fewer, longer tasks = fewer pieces to reduce
+    long long want = 4096 / ((long long)*n_cg * *n_cb);
     want = want < 1 ? 1 : want;
     long long rpt = (rows + want - 1) / want;
     rpt = rpt < 1 ? 1 : rpt;
@@ -182,7 +215,7 @@ int conv3_wgrad(const float *x, const float *dy, float *dw, int F, int H, int W,
     hipLaunchKernelGGL(conv3_wgrad_kernel, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, st, x, dy, ws, F, H, W, Cin, Cout, rpt, n_rc, n_cg, tasks);
     EDV_LAUNCH_OK();
     const int n = Cout * 9 * Cin;
-    hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, st, ws, dw, Cin, Cout, n_rc, n_cg, accumulate ? 1 : 0);
+    hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, st, ws, dw, Cin, Cout, n_rc, n_cg, accumulate ? 1 : 0);
     EDV_LAUNCH_OK();
     return 0;
 }
@@ -206,7 +239,7 @@ int colsum_rows(const float *P, const float *rowscale, long long M, int N, float
     blocks = blocks < 1 ? 1 : (blocks > COLSUM_BLOCKS ? COLSUM_BLOCKS : blocks);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, st, P, rowscale, total4, n4, ws);
     EDV_LAUNCH_OK();
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3(fold ? 1 : (N + 255) / 256), dim3(256), 0, st, ws, (int)blocks, N, fold, accumulate ? 1 : 0, out);
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 31) / 32), dim3(256), 0, st, ws, (int)blocks, N, fold, accumulate ? 1 : 0, out);
     EDV_LAUNCH_OK();
     return 0;
 }

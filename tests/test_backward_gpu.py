@@ -157,6 +157,26 @@ def test_vits_gradients_full_size(lib, cuda, H, W, T, resize_from):
     print(f"\n[vits {H}x{W} T={T}] {len(names)} tensors, worst scale-relative gradient error vs the fp64 graph {worst:.2e}")
 
 
+def test_vits_conv_head_gradients_full_size(lib, cuda):
+    """The reference's default head (four HeadDepth heads, conv_depth_* trainable next to the LoRA factors) at the trainer's
+    256x320 -> (224, 280) geometry with ViT-S's real head width (features 64: 64 -> 32 -> 32 -> 1 per head), fp64 oracle graph."""
+    kwargs = dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384], image_shape=(224, 280), lora_type="dvlora")
+    model = endodav_amd.endodav(**kwargs, pretrained_path=None)
+    synth.fill_module_(model)
+    names = []
+    for n, p in model.named_parameters():
+        p.requires_grad = (".mlp.fc" in n and n.rsplit(".", 1)[-1] in ("lora_A", "lora_B")) or n.startswith("head.conv_depth_")
+        if p.requires_grad:
+            names.append(n)
+    x = torch.from_numpy(synth.synth_clip(1, 2, 256, 320, seed=3, kind="tissue"))
+    model = model.to(cuda).train()
+    gouts = upstream([(2, 1, h, w) for (h, w) in model.output_shapes()])
+    ref64, _ = oracle_grads(model, kwargs, x, names, gouts, torch.float64)
+    hip, _ = hip_grads(model, x, names, gouts, cuda)
+    worst = check(hip, ref64, tol=1e-3)
+    print(f"\n[vits conv head 224x280 T=2] {len(names)} tensors, worst scale-relative gradient error vs the fp64 graph {worst:.2e}")
+
+
 def test_training_forward_equals_inference(lib, cuda):
     """Same kernels, same values; the inference path only orders the head differently (the fusion blocks' skip branches
     run on a second stream and are added where x is produced), which moves the result by fp32 rounding."""

@@ -81,7 +81,7 @@ SIGNATURES = {
     "edv_attn_spatial_workspace": (C.c_size_t, [_i32, _i32, _i32]),
     "edv_attn_spatial": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _fp, C.c_size_t, _fp, C.c_void_p]),
     "edv_set_train": (C.c_int, [C.c_void_p, _i32]),
-    "edv_set_grad_scope": (C.c_int, [C.c_void_p, _i32, _i32, _i32]),
+    "edv_set_grad_scope": (C.c_int, [C.c_void_p, _i32, _i32, _i32, _i32]),
     "edv_backward": (C.c_int, [C.c_void_p, _fp, C.POINTER(C.c_void_p), C.c_void_p]),
     "edv_grad": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(_i64)]),
     "edv_grad_copy": (C.c_int, [C.c_void_p, C.c_char_p, _fp, _i64, C.c_void_p]),

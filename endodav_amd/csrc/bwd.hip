@@ -680,7 +680,7 @@ __global__ __launch_bounds__(256) void ssb_prep_kernel(const float *__restrict__
     if (i < (long long)nout * nin) Wa[i] = W[i] * a[i % nin];
     if (i < nout) gb[i] = b[i] * (gamma ? gamma[i] : 1.f);
 }
-// part[s, n] = sum_{m in split s} P[m, n] * Q[m, n]
+// part[s, n] = sum_{m in split s} P[m, n] * Q[m, n]   (Q = null: P[m, n])
 __global__ __launch_bounds__(256) void col_dot_partial_kernel(const float *__restrict__ P, const float *__restrict__ Q, long long M, int N,
                                                               float *__restrict__ part, int rows_per_split) {
     __shared__ float red[4][64];
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(256) void col_dot_partial_kernel(const float *__res
     const long long me = mb + rows_per_split < M ? mb + rows_per_split : M;
     float acc = 0.f;
     if (n < N)
-        for (long long m = mb + wv; m < me; m += 4) acc += P[m * N + n] * Q[m * N + n];
+        for (long long m = mb + wv; m < me; m += 4) acc += Q ? P[m * N + n] * Q[m * N + n] : P[m * N + n];
     red[wv][lane] = acc;
     __syncthreads();
     if (wv == 0 && n < N) part[(long long)blockIdx.y * N + n] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
@@ -819,7 +819,7 @@ int ssb_prep(const float *W, const float *a, const float *b, const float *gamma,
 
 // out[n] = scale[n] * sum_m P[m, n] Q[m, n]  (deterministic two-stage reduction; part: TALL_SPLITS * N floats)
 int col_dot(const float *P, const float *Q, long long M, int N, const float *scale, float *part, float *out, hipStream_t st) {
-    EDV_CHECK(P && Q && part && out && M > 0 && N > 0, "shape");
+    EDV_CHECK(P && part && out && M > 0 && N > 0, "shape");  // Q may be null: plain column sums
     const int rows_per_split = (int)((M + TALL_SPLITS - 1) / TALL_SPLITS);
     const int splits = (int)((M + rows_per_split - 1) / rows_per_split);
     hipLaunchKernelGGL(col_dot_partial_kernel, dim3((N + 63) / 64, splits), dim3(256), 0, st, P, Q, M, N, part, rows_per_split);

@@ -71,6 +71,7 @@ struct edv_ctx {
     bool have_saved = false;      // a training forward has run since the last backward
     bool grad_encoder = true;     // which factor gradients the caller wants (edv_set_grad_scope): the trainer alternates
     bool grad_temporal = true;    // spatial and temporal tuning phases (trainer_end_to_end_video.py:327-339)
+    bool grad_res = false;        // parameters of the residual bottleneck blocks (residual_*, trainable by default in the reference)
     bool grad_head = false;       // weight / bias gradients of the output-head convolutions (conv_depth_*, or scratch.output_conv* with --train_output_conv)
     std::unordered_map<std::string, Buf> grads;  // gradients of the trainable parameters, owned
     int launches = 0;
@@ -608,6 +609,122 @@ struct Run {
         return 0;
     }
 
+    // Training form of res_bottleneck: the same arithmetic, with LayerNorm and GELU as separate launches so that every
+    // intermediate the backward needs is kept (rows = F * 320 patch tokens only: the blocks exist at image_shape (224, 280)).
+    int res_bottleneck_train(int i, float *xt) {
+        EDV_CHECK(ph == 16 && pw == 20, "shape '[B, 16, 20, C]' is invalid for the patch tokens: residual blocks need image_shape (224, 280)");
+        const std::string p = "pretrained.blocks." + std::to_string(i) + ".residual_", tg = "rbt" + std::to_string(i) + ".";
+        const int Cb = D / 8;
+        const long long MP = (long long)F * P0;
+        float *xp, *t1a, *ln1, *a1, *t1b, *ln2, *a2, *t3;
+        EDV_TRY(wsbuf(tg + "xp", (size_t)MP * D, &xp));
+        EDV_TRY(wsbuf(tg + "t1a", (size_t)MP * Cb, &t1a));
+        EDV_TRY(wsbuf(tg + "ln1", (size_t)MP * Cb, &ln1));
+        EDV_TRY(wsbuf(tg + "a1", (size_t)MP * Cb, &a1));
+        EDV_TRY(wsbuf(tg + "t1b", (size_t)MP * Cb, &t1b));
+        EDV_TRY(wsbuf(tg + "ln2", (size_t)MP * Cb, &ln2));
+        EDV_TRY(wsbuf(tg + "a2", (size_t)MP * Cb, &a2));
+        EDV_TRY(wsbuf(tg + "t3", (size_t)MP * D, &t3));
+        for (int f = 0; f < F; ++f)  // the patch rows of the residual stream, compact (block.py:146: .clone())
+            EDV_TRY(copy_f32(xt + ((size_t)f * ntok + c0) * D, xp + (size_t)f * P0 * D, (long long)P0 * D, st));
+        const float *w, *nw, *nb;
+        EDV_TRY(param(p + ".conv1.weight", &w, 4));
+        EDV_TRY(linear(xp, MP, D, w, Cb, nullptr, t1a));
+        EDV_TRY(param(p + ".norm1.weight", &nw));
+        EDV_TRY(param(p + ".norm1.bias", &nb));
+        EDV_TRY(layernorm(t1a, identity_map(), nw, nb, ln1, identity_map(), MP, Cb, 1e-6f, nullptr, 0, 0, st));
+        EDV_TRY(ew_bwd(ln1, nullptr, nullptr, a1, MP * Cb, 3, st));
+        EDV_TRY(packedw(p + ".conv2.weight", &w));
+        EDV_TRY(conv3(a1, ph, pw, Cb, w, nullptr, Cb, 1, t1b, false));
+        EDV_TRY(param(p + ".norm2.weight", &nw));
+        EDV_TRY(param(p + ".norm2.bias", &nb));
+        EDV_TRY(layernorm(t1b, identity_map(), nw, nb, ln2, identity_map(), MP, Cb, 1e-6f, nullptr, 0, 0, st));
+        EDV_TRY(ew_bwd(ln2, nullptr, nullptr, a2, MP * Cb, 3, st));
+        EDV_TRY(param(p + ".conv3.weight", &w, 4));
+        EDV_TRY(linear(a2, MP, Cb, w, D, nullptr, t3));
+        EDV_TRY(param(p + ".norm3.weight", &nw));
+        EDV_TRY(param(p + ".norm3.bias", &nb));
+        EDV_TRY(layernorm(t3, identity_map(), nw, nb, xt, RowMap{P0, ntok, c0}, MP, D, 1e-6f, nullptr, 0, 0, st, ACT_NONE, true));
+        c->launches += 5 + F;
+        return 0;
+    }
+    // y = LN(x) * w + b over `dim` channels: input gradient into dx, and (grad_res) dL/dw = colsum(dy * xhat), dL/db = colsum(dy)
+    int ln_affine_bwd(const std::string &norm, const float *x, const float *dy, float *dx, long long rows, int dim) {
+        const float *w;
+        EDV_TRY(param(norm + ".weight", &w));
+        EDV_TRY(layernorm_bwd(x, identity_map(), w, dy, identity_map(), dx, identity_map(), rows, dim, 1e-6f, false, st));
+        if (!c->grad_res) return 0;
+        float *ones, *zeros, *xhat, *part, *dw, *db;
+        EDV_TRY(wsbuf("g.rb.ones", (size_t)D, &ones));
+        EDV_TRY(wsbuf("g.rb.zeros", (size_t)D, &zeros));
+        EDV_HIP(hipMemsetD32Async((hipDeviceptr_t)ones, 0x3f800000, (size_t)D, st));
+        EDV_HIP(hipMemsetAsync(zeros, 0, (size_t)D * sizeof(float), st));
+        EDV_TRY(wsbuf("g.rb.xhat", (size_t)rows * D, &xhat));
+        EDV_TRY(wsbuf("g.rb.part", (size_t)TALL_SPLITS * D, &part));
+        EDV_TRY(gradbuf(norm + ".weight", (size_t)dim, &dw));
+        EDV_TRY(gradbuf(norm + ".bias", (size_t)dim, &db));
+        EDV_TRY(layernorm(x, identity_map(), ones, zeros, xhat, identity_map(), rows, dim, 1e-6f, nullptr, 0, 0, st));
+        EDV_TRY(col_dot(dy, xhat, rows, dim, nullptr, part, dw, st));
+        EDV_TRY(col_dot(dy, nullptr, rows, dim, nullptr, part, db, st));
+        return 0;
+    }
+    // dW[N, K] = dY^T X for a 1x1 convolution / linear without bias (dY [M, N], X [M, K]): both operands transposed, then the NT GEMM
+    int linear_wgrad(const std::string &name, const float *dY, int N, const float *X, int K, long long M) {
+        if (!c->grad_res) return 0;
+        float *dyt, *xt_, *dw;
+        EDV_TRY(wsbuf("g.rb.dyt", (size_t)M * D, &dyt));
+        EDV_TRY(wsbuf("g.rb.xt", (size_t)M * D, &xt_));
+        EDV_TRY(gradbuf(name, (size_t)N * K, &dw));
+        EDV_TRY(transpose_scale(dY, N, nullptr, dyt, (int)M, N, st));  // [M, N] -> [N, M]
+        EDV_TRY(transpose_scale(X, K, nullptr, xt_, (int)M, K, st));   // [M, K] -> [K, M]
+        return linear(dyt, N, (int)M, xt_, K, nullptr, dw);
+    }
+    // backward of the residual block of encoder block i: dxt (gradient of the block output, [F*ntok, D]) gains, on its patch rows,
+    // the gradient that flows through conv1 .. norm3 (the identity path is already in dxt)
+    int res_bottleneck_bwd(int i, float *dxt) {
+        const std::string p = "pretrained.blocks." + std::to_string(i) + ".residual_", tg = "rbt" + std::to_string(i) + ".";
+        const int Cb = D / 8;
+        const long long MP = (long long)F * P0;
+        const float *xp, *t1a, *ln1, *a1, *t1b, *ln2, *a2, *t3;
+        EDV_TRY(saved(tg + "xp", &xp));
+        EDV_TRY(saved(tg + "t1a", &t1a));
+        EDV_TRY(saved(tg + "ln1", &ln1));
+        EDV_TRY(saved(tg + "a1", &a1));
+        EDV_TRY(saved(tg + "t1b", &t1b));
+        EDV_TRY(saved(tg + "ln2", &ln2));
+        EDV_TRY(saved(tg + "a2", &a2));
+        EDV_TRY(saved(tg + "t3", &t3));
+        float *dout, *dD, *dC1, *dC2;
+        EDV_TRY(wsbuf("g.rb.dout", (size_t)MP * D, &dout));
+        EDV_TRY(wsbuf("g.rb.dD", (size_t)MP * D, &dD));
+        EDV_TRY(wsbuf("g.rb.dC1", (size_t)MP * Cb, &dC1));
+        EDV_TRY(wsbuf("g.rb.dC2", (size_t)MP * Cb, &dC2));
+        for (int f = 0; f < F; ++f) EDV_TRY(copy_f32(dxt + ((size_t)f * ntok + c0) * D, dout + (size_t)f * P0 * D, (long long)P0 * D, st));
+        EDV_TRY(ln_affine_bwd(p + ".norm3", t3, dout, dD, MP, D));                 // out = LN3(t3)
+        EDV_TRY(linear_wgrad(p + ".conv3.weight", dD, D, a2, Cb, MP));            // t3 = a2 W3^T
+        EDV_TRY(dgemm(dD, MP, D, p + ".conv3", Cb, dC1));
+        EDV_TRY(ew_bwd(dC1, ln2, nullptr, dC1, MP * Cb, 1, st));                   // a2 = gelu(ln2)
+        EDV_TRY(ln_affine_bwd(p + ".norm2", t1b, dC1, dC2, MP, Cb));              // ln2 = LN2(t1b)
+        if (c->grad_res) {
+            float *dw, *ws;
+            EDV_TRY(gradbuf(p + ".conv2.weight", (size_t)Cb * Cb * 9, &dw));
+            const size_t need = conv3_wgrad_workspace(F, ph, pw, Cb, Cb);
+            EDV_TRY(wsbuf("g.wgrad", need, &ws));
+            EDV_TRY(conv3_wgrad(a1, dC2, dw, F, ph, pw, Cb, Cb, ws, need, false, st));  // t1b = conv2(a1)
+        }
+        EDV_TRY(dconv3(dC2, ph, pw, Cb, p + ".conv2", Cb, dC1));
+        EDV_TRY(ew_bwd(dC1, ln1, nullptr, dC1, MP * Cb, 1, st));                   // a1 = gelu(ln1)
+        EDV_TRY(ln_affine_bwd(p + ".norm1", t1a, dC1, dC2, MP, Cb));              // ln1 = LN1(t1a)
+        EDV_TRY(linear_wgrad(p + ".conv1.weight", dC2, Cb, xp, D, MP));           // t1a = xp W1^T
+        EDV_TRY(dgemm(dC2, MP, Cb, p + ".conv1", D, dD));
+        for (int f = 0; f < F; ++f) {  // patch rows of dxt += the branch's input gradient
+            float *dst = dxt + ((size_t)f * ntok + c0) * D;
+            EDV_TRY(ew_bwd(dD + (size_t)f * P0 * D, nullptr, dst, dst, (long long)P0 * D, 0, st));
+        }
+        c->launches += 20 + 2 * F;
+        return 0;
+    }
+
     struct EncBufs {
         float *cols, *xt, *xn, *qkv, *att, *hid;
         float *tap[4], *tapcls[4];
@@ -714,7 +831,7 @@ struct Run {
             EDV_TRY(param(bp + ".ls2.gamma", &gam));
             EDV_TRY(linear(hid, MT, 4 * D, w, D, b, x_out, ACT_NONE, gam, x_mid));
             xt = x_out;
-            if (cfg.residual_mask & (1u << i)) EDV_TRY(res_bottleneck(i, xt));
+            if (cfg.residual_mask & (1u << i)) EDV_TRY(c->train ? res_bottleneck_train(i, xt) : res_bottleneck(i, xt));
             if (i == 0) EDV_TRY(snapshot("block0", xt, (size_t)MT * D));
             if (tapj < 4 && i == cfg.taps[tapj]) {
                 // final norm on the tap, cls row dropped (vision_transformer.py:317-321)
@@ -1104,7 +1221,7 @@ struct Run {
     int prepare_train() {
         EDV_CHECK(!cfg.use_bn, "the fine-tune step with use_bn=True is not built (train-mode BatchNorm uses batch statistics)");
         EDV_CHECK(c->prepared, "edv_prepare has not run");
-        EDV_CHECK(!cfg.use_clstoken && !cfg.residual_mask && !cfg.out_sigmoid, "training does not support use_clstoken / residual blocks / out_sigmoid");
+        EDV_CHECK(!cfg.use_clstoken && !cfg.out_sigmoid, "training does not support use_clstoken / out_sigmoid");
         EDV_CHECK(cfg.lora_type != EDV_LORA_DASH, "training supports lora_type none, lora, dvlora and ssb");
         const int *oc = cfg.out_channels;
         for (int i = 0; i < depth; ++i) {
@@ -1117,6 +1234,13 @@ struct Run {
             EDV_TRY(make_t_lin(bp + ".mlp.fc1"));
             EDV_TRY(make_t_lin(bp + ".mlp.fc2", g2));
         }
+        for (int i = 0; i < depth; ++i)
+            if (cfg.residual_mask & (1u << i)) {
+                const std::string rp = "pretrained.blocks." + std::to_string(i) + ".residual_";
+                EDV_TRY(make_t_lin(rp + ".conv1"));
+                EDV_TRY(make_t_lin(rp + ".conv3"));
+                EDV_TRY(make_b_c3(rp + ".conv2"));
+            }
         for (int j = 0; j < 4; ++j) EDV_TRY(make_t_lin("head.projects." + std::to_string(j)));
         for (int j = 0; j < 2; ++j) {
             const std::string rp = "head.resize_layers." + std::to_string(j);
@@ -1410,7 +1534,8 @@ struct Run {
         }
         EDV_TRY(motion_module_bwd(0, d_l[3], h3 * w3, oc[2]));
         EDV_TRY(motion_module_bwd(1, d_l[4], h4 * w4, oc[3]));
-        if (!c->grad_encoder || cfg.lora_type == EDV_LORA_NONE) {  // temporal-only phase: nothing trainable below the head
+        const bool res_grads = c->grad_res && cfg.residual_mask != 0;
+        if ((!c->grad_encoder || cfg.lora_type == EDV_LORA_NONE) && !res_grads) {  // temporal-only phase: nothing trainable below the head
             c->have_saved = false;
             return 0;
         }
@@ -1453,7 +1578,7 @@ struct Run {
         const size_t abws_n = attn_spatial_bwd_workspace(F, ntok, heads);
         if (abws_n) EDV_TRY(wsbuf("g.attbws", abws_n, &abws));
         const int rank = cfg.lora_rank;
-        const bool lora = cfg.lora_type != EDV_LORA_NONE;
+        const bool lora = cfg.lora_type != EDV_LORA_NONE && c->grad_encoder;
         const size_t lws_n = lora_ws_n;
         lws = lora_ws;
         EDV_HIP(hipMemsetAsync(dxt, 0, (size_t)MT * D * sizeof(float), st));
@@ -1477,7 +1602,8 @@ struct Run {
                 EDV_TRY(layernorm_bwd(x_out, RowMap{P0, ntok, c0}, nw, d_tap[tapj], identity_map(), dxt, RowMap{P0, ntok, c0}, MP, D, 1e-6f, true, st));
                 --tapj;
             }
-            // x_out = x_mid + ls2 * fc2(gelu(fc1(norm2(x_mid))))
+            if (cfg.residual_mask & (1u << i)) EDV_TRY(res_bottleneck_bwd(i, dxt));  // x_out = x' + residual_(x' patch rows)
+            // x' = x_mid + ls2 * fc2(gelu(fc1(norm2(x_mid))))
             if (lora) EDV_TRY(lora_step(bp + ".mlp.fc2", hid, 4 * D, dxt, D, MT, rank, lscale, bp + ".ls2.gamma", lws, lws_n));
             EDV_TRY(dgemm(dxt, MT, D, bp + ".mlp.fc2", 4 * D, t4));
             EDV_TRY(ew_bwd(t4, pre, nullptr, t4, MT * 4 * D, 1, st));
@@ -1644,7 +1770,7 @@ int edv_forward(edv_ctx *ctx, const float *x_dev, int32_t B, int32_t T, int32_t 
     for (int k = 0; k < 4; ++k) EDV_CHECK(disp_dev[k], "null output");
     if (ctx->train) {
         const edv_config &c = ctx->cfg;
-        EDV_CHECK(!c.use_clstoken && !c.residual_mask && !c.out_sigmoid, "training does not support use_clstoken / residual blocks / out_sigmoid");
+        EDV_CHECK(!c.use_clstoken && !c.out_sigmoid, "training does not support use_clstoken / out_sigmoid");
         EDV_CHECK(c.lora_type != EDV_LORA_DASH, "training supports lora_type none, lora, dvlora and ssb");
         EDV_CHECK(!ctx->capture, "stage capture and training are exclusive");
     }
@@ -1668,8 +1794,9 @@ int edv_set_encoder_streams(edv_ctx *ctx, int32_t n) {
     return 0;
 }
 
-int edv_set_grad_scope(edv_ctx *ctx, int32_t encoder_factors, int32_t temporal_factors, int32_t head_convs) {
+int edv_set_grad_scope(edv_ctx *ctx, int32_t encoder_factors, int32_t temporal_factors, int32_t head_convs, int32_t residual_blocks) {
     EDV_CHECK(ctx, "null context");
+    ctx->grad_res = residual_blocks != 0;
     ctx->grad_encoder = encoder_factors != 0;
     ctx->grad_temporal = temporal_factors != 0;
     ctx->grad_head = head_convs != 0;

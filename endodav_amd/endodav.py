@@ -392,7 +392,8 @@ class _EdvFunction(torch.autograd.Function):
             enc = any(".mlp.fc" in n for n in ctx.names)
             tmp = any(".ff.net.2." in n for n in ctx.names)
             hd = any(_is_head_conv(n) for n in ctx.names)
-            _lib.check(lib.edv_set_grad_scope(C.c_void_p(ctx.handle), int(enc), int(tmp), int(hd)), "edv_set_grad_scope")
+            rb = any(".residual_." in n for n in ctx.names)
+            _lib.check(lib.edv_set_grad_scope(C.c_void_p(ctx.handle), int(enc), int(tmp), int(hd), int(rb)), "edv_set_grad_scope")
             _lib.check(lib.edv_backward(C.c_void_p(ctx.handle), disp0.data_ptr(), ptrs, stream), "edv_backward")
             grads = []
             for name, shp in zip(ctx.names, ctx.param_shapes):
@@ -616,11 +617,11 @@ class endodav(nn.Module):
         gradients of the LoRA factors of mlp.fc1 / mlp.fc2 (what ``mark_only_part_as_trainable`` leaves trainable for
         lora / dvlora, endodav/layers.py:5-34); a trainable parameter outside that set is refused, not silently frozen."""
         names = [n for n, p in self.state_dict(keep_vars=True).items() if p.requires_grad]
-        bad = [n for n in names if not (_is_lora_factor(n) or _is_head_conv(n))]
+        bad = [n for n in names if not (_is_lora_factor(n) or _is_head_conv(n) or (n.startswith("pretrained.blocks.") and ".residual_." in n))]
         if bad:
             raise NotImplementedError(f"libendodav_hip has no gradient for {bad[:4]}{' ...' if len(bad) > 4 else ''}: the HIP backward covers the LoRA "
-                                      "factors of the encoder MLPs (and, with temporal_lora, of ff.net.2 in the motion modules) and the output-head "
-                                      "convolutions conv_depth_* / scratch.output_conv* (SURVEY.md §8f rank 3)")
+                                      "factors of the encoder MLPs (and, with temporal_lora, of ff.net.2 in the motion modules), the residual bottleneck "
+                                      "blocks residual_* and the output-head convolutions conv_depth_* / scratch.output_conv* (SURVEY.md §8f rank 3)")
         if any(_is_lora_factor(n) for n in names) and self.lora_type not in ("lora", "dvlora", "ssb"):
             raise NotImplementedError(f"the HIP backward supports lora_type 'lora', 'dvlora' and 'ssb', not {self.lora_type!r}")
         return names

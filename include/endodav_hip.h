@@ -238,8 +238,10 @@ int edv_set_train(edv_ctx *ctx, int32_t on);
  * trainable), with temporal_factors = 0 the ff.net.2 products are skipped.  head_convs != 0 adds the weight and bias gradients of
  * the output-head convolutions, named like the state_dict: "head.conv_depth_<k>.head.{0,2,4}.{weight,bias}" with the conv head
  * (trainable by default, endodav/layers.py:5-34), "head.scratch.output_conv1.*", "head.scratch.output_conv2.{0,2}.*" with the VDA
- * head (--train_output_conv).  Default: both factor sets, no head convolutions. */
-int edv_set_grad_scope(edv_ctx *ctx, int32_t encoder_factors, int32_t temporal_factors, int32_t head_convs);
+ * head (--train_output_conv).  residual_blocks != 0 adds every parameter of the ResBottleneckBlocks
+ * ("pretrained.blocks.<i>.residual_.{conv1,conv2,conv3}.weight", ".norm{1,2,3}.{weight,bias}"; trainable by default in the reference,
+ * block.py:146-150).  Default: both factor sets, nothing else. */
+int edv_set_grad_scope(edv_ctx *ctx, int32_t encoder_factors, int32_t temporal_factors, int32_t head_convs, int32_t residual_blocks);
 int edv_backward(edv_ctx *ctx, const float *disp0_dev, const float *const grad_disp_dev[4], void *stream);
 int edv_grad(edv_ctx *ctx, const char *name, float **grad_dev, int64_t *numel);
 int edv_grad_copy(edv_ctx *ctx, const char *name, float *dst_dev, int64_t numel, void *stream); /* stream-ordered copy into caller memory */

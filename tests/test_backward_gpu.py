@@ -177,6 +177,25 @@ def test_vits_conv_head_gradients_full_size(lib, cuda):
     print(f"\n[vits conv head 224x280 T=2] {len(names)} tensors, worst scale-relative gradient error vs the fp64 graph {worst:.2e}")
 
 
+def test_reference_default_trainable_set_gradients(lib, cuda):
+    """What the reference trains with its default options (no --disable_* flags; trainer_end_to_end_video.py:337 ->
+    endodav/layers.py:5-34): LoRA A/B of every MLP, every parameter of the ResBottleneckBlocks in encoder blocks 2/5/8/11
+    (residual_*; they exist at image_shape (224, 280) only) and the four HeadDepth heads (conv_depth_*).  The trainable set is the
+    one mark_only_part_as_trainable leaves, unchanged; fp64 oracle graph."""
+    kwargs = dict(encoder="vits", features=32, out_channels=[32, 32, 64, 64], image_shape=(224, 280), lora_type="dvlora", residual_block_indexes=[2, 5, 8, 11])
+    model = endodav_amd.endodav(**kwargs, pretrained_path=None)
+    synth.fill_module_(model)
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    assert sum(".residual_." in n for n in names) == 4 * 9 and sum("conv_depth_" in n for n in names) == 24 and sum("lora_" in n for n in names) == 48
+    x = torch.from_numpy(synth.synth_clip(1, 2, 224, 280, seed=3, kind="tissue"))
+    model = model.to(cuda).train()
+    gouts = upstream([(2, 1, h, w) for (h, w) in model.output_shapes()])
+    ref64, _ = oracle_grads(model, kwargs, x, names, gouts, torch.float64)
+    hip, _ = hip_grads(model, x, names, gouts, cuda)
+    worst = check(hip, ref64, tol=1e-3)
+    print(f"\n[reference default trainable set, 224x280 T=2] {len(names)} tensors, worst scale-relative gradient error vs the fp64 graph {worst:.2e}")
+
+
 def test_training_forward_equals_inference(lib, cuda):
     """Same kernels, same values; the inference path only orders the head differently (the fusion blocks' skip branches
     run on a second stream and are added where x is produced), which moves the result by fp32 rounding."""

@@ -349,8 +349,9 @@ struct Run {
         return 0;
     }
 
-    // After an optimizer step only the LoRA factors changed: re-fold the linears that carry them (and, once the backward has
-    // run, their transposes) instead of re-packing every frozen weight as edv_prepare does.
+    // After an optimizer step only trainable tensors changed: re-fold the linears that carry LoRA factors and re-pack the trainable
+    // convolutions (HeadDepth heads or scratch.output_conv*, residual blocks) -- and, once the backward has run, their transposed /
+    // flipped copies -- instead of re-packing every frozen weight as edv_prepare does.
     int refresh_lora() {
         EDV_CHECK(c->prepared, "edv_prepare has not run");
         for (int i = 0; i < depth; ++i) {
@@ -363,6 +364,14 @@ struct Run {
                 EDV_TRY(make_t_lin(bp + ".mlp.fc1"));
                 EDV_TRY(make_t_lin(bp + ".mlp.fc2", g2));
             }
+            if (cfg.residual_mask & (1u << i)) {
+                EDV_TRY(pack_c3(bp + ".residual_.conv2"));
+                if (c->train_prepared) {
+                    EDV_TRY(make_t_lin(bp + ".residual_.conv1"));
+                    EDV_TRY(make_t_lin(bp + ".residual_.conv3"));
+                    EDV_TRY(make_b_c3(bp + ".residual_.conv2"));
+                }
+            }
         }
         if (cfg.temporal_lora)
             for (int m = 0; m < 4; ++m) {
@@ -370,6 +379,19 @@ struct Run {
                 EDV_TRY(fold_linear(p, true));
                 if (c->train_prepared) EDV_TRY(make_t_lin(p));
             }
+        std::vector<std::string> convs;
+        if (cfg.conv_head) {
+            for (int k = 1; k <= 4; ++k) {
+                convs.push_back("head.conv_depth_" + std::to_string(k) + ".head.0");
+                convs.push_back("head.conv_depth_" + std::to_string(k) + ".head.2");
+            }
+        } else {
+            convs = {"head.scratch.output_conv1", "head.scratch.output_conv2.0"};
+        }
+        for (const std::string &cv : convs) {
+            EDV_TRY(pack_c3(cv));
+            if (c->train_prepared) EDV_TRY(make_b_c3(cv));
+        }
         return 0;
     }
 

@@ -514,9 +514,9 @@ class endodav(nn.Module):
         if self.pe == "rope":  # the rotary tables are not state (motion_module.py:221-225) but the engine reads them like weights
             sd.update({k: v for k, v in self.named_buffers() if k.endswith(".freqs_cis")})
         sig = tuple((k, v.data_ptr(), v._version) for k, v in sd.items())
-        if sig != nat.sig and nat.sig is not None and len(sig) == len(nat.sig) and self.lora_type in ("lora", "dvlora", "ssb") and all(
-                a[:2] == b[:2] and (a[2] == b[2] or _is_lora_factor(a[0])) for a, b in zip(sig, nat.sig)):
-            # the fine-tune loop: same tensors, only LoRA factors written (optimizer.step) -> re-fold those linears only
+        if sig != nat.sig and nat.sig is not None and len(sig) == len(nat.sig) and self.lora_type != "dash" and all(
+                a[:2] == b[:2] and (a[2] == b[2] or _is_lora_factor(a[0]) or _is_head_conv(a[0]) or ".residual_." in a[0]) for a, b in zip(sig, nat.sig)):
+            # the fine-tune loop: same tensors, only trainable ones written (optimizer.step) -> re-fold / re-pack those only
             _lib.check(lib.edv_refresh_lora(C.c_void_p(nat.handle), C.c_void_p(_lib.stream_ptr(device))), "edv_refresh_lora")
             nat.sig = sig
         if sig != nat.sig:

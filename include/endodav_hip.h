@@ -84,9 +84,10 @@ int edv_bind_param(edv_ctx *ctx, const char *name, const float *data_dev, const 
 int edv_prepare(edv_ctx *ctx, void *stream);
 
 /* The cheap form of edv_prepare for the fine-tune loop (trainer_end_to_end_video.py:427-431: only the optimizer writes, and only
- * into the LoRA factors): re-folds the linears that carry LoRA factors (mlp.fc1/fc2 of every block and, with temporal_lora, ff.net.2
- * of the motion modules) and, once a backward has run, their transposed copies.  Everything frozen keeps its packing.  Valid only
- * when no bound pointer changed and only lora_A/B/U/V contents did; otherwise call edv_prepare. */
+ * into trainable tensors): re-folds the linears that carry LoRA factors (mlp.fc1/fc2 of every block and, with temporal_lora, ff.net.2
+ * of the motion modules), re-packs the trainable convolutions (conv_depth_* or scratch.output_conv*, residual_*) and, once a backward
+ * has run, their transposed / flipped copies.  Everything frozen keeps its packing.  Valid only when no bound pointer changed and
+ * only those tensors' contents did; otherwise call edv_prepare. */
 int edv_refresh_lora(edv_ctx *ctx, void *stream);
 
 /* endodav.forward (endodav.py:150-160).  x_dev: [B,T,3,H,W] fp32 in [0,1].  disp_dev[s] receives

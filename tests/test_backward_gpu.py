@@ -291,13 +291,41 @@ def test_optimizer_step_is_seen_by_the_next_forward(lib, cuda):
     assert losses[-1] < losses[0], losses  # plain gradient descent on a quadratic of the output
 
 
+def test_refresh_after_optimizer_step_equals_a_full_prepare(lib, cuda):
+    """After optimizer.step() the host sees that only trainable tensors changed version and calls edv_refresh_lora (LoRA folds, the
+    trainable convolutions' packings and their backward copies) instead of edv_prepare.  The refreshed context must behave exactly
+    like a freshly prepared one: same outputs, same gradients, bit for bit."""
+    kwargs = dict(encoder="vits", features=32, out_channels=[32, 32, 64, 64], image_shape=(224, 280), lora_type="dvlora", residual_block_indexes=[2, 5, 8, 11])
+    model = endodav_amd.endodav(**kwargs, pretrained_path=None)
+    synth.fill_module_(model)
+    model = model.to(cuda).train()
+    x = torch.from_numpy(synth.synth_clip(1, 2, 224, 280, seed=4, kind="tissue")).to(cuda)
+    params = [p for p in model.parameters() if p.requires_grad]
+    opt = torch.optim.SGD(params, lr=1e-3)
+
+    def step_grads():
+        model.zero_grad(set_to_none=True)
+        out = model(x)
+        sum((o * o).mean() for o in out.values()).backward()
+        return [o.detach().clone() for o in out.values()], [p.grad.detach().clone() for p in params]
+
+    for _ in range(3):
+        step_grads()
+        opt.step()
+    out_a, g_a = step_grads()          # context kept across the steps: refresh path
+    model._native.clear()              # drop it: the next forward binds and prepares from scratch
+    out_b, g_b = step_grads()
+    assert all(torch.equal(a, b) for a, b in zip(out_a, out_b))
+    assert all(torch.equal(a, b) for a, b in zip(g_a, g_b))
+
+
 def test_unsupported_trainable_parameters_are_refused(lib, cuda):
     model, kwargs, shape, kind, _ = build_model("micro_vda_dvlora")
     x = case_input("micro_vda_dvlora").to(cuda)
     model = model.to(cuda)
     for p in model.parameters():
         p.requires_grad = False
-    model.get_parameter("head.scratch.output_conv1.weight").requires_grad = True
+    model.get_parameter("head.scratch.layer1_rn.weight").requires_grad = True
     with pytest.raises(NotImplementedError, match="no gradient for"):
         model(x)
     with torch.no_grad():

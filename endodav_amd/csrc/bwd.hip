@@ -103,6 +103,14 @@ __global__ __launch_bounds__(256) void ew_bwd_kernel(const float *__restrict__ d
     }
 }
 
+// out = g * s * (1 - s): through y = sigmoid(z) given y (out_sigmoid of the VDA head, dpt_pyramid.py:97-101); any n
+__global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float *__restrict__ g, const float *__restrict__ s, float *__restrict__ out, long long n) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+        const float y = s[i];
+        out[i] = g[i] * (y * (1.f - y));
+    }
+}
+
 // GEGLU backward (temporal.hip geglu_kernel): y = a * gelu(g);  x rows are [a (inner) | g (inner)]
 __global__ __launch_bounds__(256) void geglu_bwd_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ dx, long long total4,
                                                         int inner4) {
@@ -715,6 +723,13 @@ int ew_bwd(const float *d, const float *src, const float *add, float *out, long 
     EDV_CHECK(d && out && n > 0 && n % 4 == 0, "shape");
     EDV_CHECK(mode >= 0 && mode <= 3 && (mode == 0 || mode == 3 || src), "mode");
     hipLaunchKernelGGL(ew_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, st, d, src, add, out, n / 4, mode);
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
+int sigmoid_bwd(const float *g, const float *s, float *out, long long n, hipStream_t st) {
+    EDV_CHECK(g && s && out && n > 0, "shape");
+    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, g, s, out, n);
     EDV_LAUNCH_OK();
     return 0;
 }

@@ -1162,9 +1162,19 @@ struct Run {
             }
             c->launches += 5;
             if (cfg.out_sigmoid) {
+                if (c->train) {  // the backward needs the ReLU mask of the raw map and every sigmoid output
+                    float *raw0;
+                    EDV_TRY(wsbuf("hd.raw0", (size_t)F * ih * iw, &raw0));
+                    EDV_TRY(copy_f32(disp[0], raw0, (long long)F * ih * iw, st));
+                }
                 sh = ih; sw = iw;
                 for (int k = 0; k < 4; ++k) {
                     EDV_TRY(sigmoid_inplace(disp[k], (long long)F * sh * sw, st));
+                    if (c->train) {
+                        float *sg;
+                        EDV_TRY(wsbuf("hd.sg" + std::to_string(k), (size_t)F * sh * sw, &sg));
+                        EDV_TRY(copy_f32(disp[k], sg, (long long)F * sh * sw, st));
+                    }
                     sh /= 2; sw /= 2;
                 }
                 c->launches += 4;
@@ -1243,7 +1253,7 @@ struct Run {
     int prepare_train() {
         EDV_CHECK(!cfg.use_bn, "the fine-tune step with use_bn=True is not built (train-mode BatchNorm uses batch statistics)");
         EDV_CHECK(c->prepared, "edv_prepare has not run");
-        EDV_CHECK(!cfg.use_clstoken && !cfg.out_sigmoid, "training does not support use_clstoken / out_sigmoid");
+        EDV_CHECK(!cfg.use_clstoken, "training does not support use_clstoken");
         EDV_CHECK(cfg.lora_type != EDV_LORA_DASH, "training supports lora_type none, lora, dvlora and ssb");
         const int *oc = cfg.out_channels;
         for (int i = 0; i < depth; ++i) {
@@ -1504,10 +1514,26 @@ struct Run {
             sh[0] = ih; sw[0] = iw;
             for (int k = 1; k < 4; ++k) { sh[k] = sh[k - 1] / 2; sw[k] = sw[k - 1] / 2; }
             float *gd[3];
+            const float *g3 = g[3], *mask0 = disp0;
+            if (cfg.out_sigmoid) {  // disp[k] = sigmoid(raw[k]) (dpt_pyramid.py:97-101): dL/d raw[k] = g[k] s (1 - s); the ReLU mask is the raw map's
+                float *g3s;
+                const float *sg;
+                EDV_TRY(wsbuf("g.d3", (size_t)F * sh[3] * sw[3], &g3s));
+                EDV_TRY(saved("hd.sg3", &sg));
+                EDV_TRY(sigmoid_bwd(g[3], sg, g3s, (long long)F * sh[3] * sw[3], st));
+                g3 = g3s;
+                EDV_TRY(saved("hd.raw0", &mask0));
+            }
             for (int k = 2; k >= 0; --k) {
                 EDV_TRY(wsbuf("g.d" + std::to_string(k), (size_t)F * sh[k] * sw[k], &gd[k]));
-                EDV_TRY(copy_f32(g[k], gd[k], (long long)F * sh[k] * sw[k], st));
-                EDV_TRY(bilinear_bwd(k == 2 ? g[3] : gd[k + 1], gd[k], F, sh[k], sw[k], 1, sh[k + 1], sw[k + 1], true, st));
+                if (cfg.out_sigmoid) {
+                    const float *sg;
+                    EDV_TRY(saved("hd.sg" + std::to_string(k), &sg));
+                    EDV_TRY(sigmoid_bwd(g[k], sg, gd[k], (long long)F * sh[k] * sw[k], st));
+                } else {
+                    EDV_TRY(copy_f32(g[k], gd[k], (long long)F * sh[k] * sw[k], st));
+                }
+                EDV_TRY(bilinear_bwd(k == 2 ? g3 : gd[k + 1], gd[k], F, sh[k], sw[k], 1, sh[k + 1], sw[k + 1], true, st));
             }
             float *d_o2, *d_up, *d_o1, *gz = nullptr;
             const float *o2, *w, *p1, *up;
@@ -1517,7 +1543,7 @@ struct Run {
             EDV_TRY(wsbuf("g.o1", (size_t)F * h0 * w0 * Fh, &d_o1));
             if (c->grad_head) EDV_TRY(wsbuf("g.gz", (size_t)F * ih * iw, &gz));  // --train_output_conv (endodav/layers.py:5-34)
             EDV_TRY(param("head.scratch.output_conv2.2.weight", &w));
-            EDV_TRY(dot_channels_bwd(gd[0], disp0, w, o2, d_o2, gz, (long long)F * ih * iw, 32, 0, st));
+            EDV_TRY(dot_channels_bwd(gd[0], mask0, w, o2, d_o2, gz, (long long)F * ih * iw, 32, 0, st));
             if (c->grad_head) {
                 EDV_TRY(saved("hd.up", &up));
                 EDV_TRY(saved("p1", &p1));
@@ -1792,7 +1818,7 @@ int edv_forward(edv_ctx *ctx, const float *x_dev, int32_t B, int32_t T, int32_t 
     for (int k = 0; k < 4; ++k) EDV_CHECK(disp_dev[k], "null output");
     if (ctx->train) {
         const edv_config &c = ctx->cfg;
-        EDV_CHECK(!c.use_clstoken && !c.out_sigmoid, "training does not support use_clstoken / out_sigmoid");
+        EDV_CHECK(!c.use_clstoken, "training does not support use_clstoken");
         EDV_CHECK(c.lora_type != EDV_LORA_DASH, "training supports lora_type none, lora, dvlora and ssb");
         EDV_CHECK(!ctx->capture, "stage capture and training are exclusive");
     }

@@ -127,6 +127,7 @@ int layernorm_bwd(const float *x, RowMap xmap, const float *w, const float *dy, 
                   bool accumulate, hipStream_t st);
 // out = f(d) + (add ? add : 0);  mode 0: f = d, 1: d * gelu'(src), 2: src > 0 ? d : 0
 int ew_bwd(const float *d, const float *src, const float *add, float *out, long long n, int mode, hipStream_t st);
+int sigmoid_bwd(const float *g, const float *s, float *out, long long n, hipStream_t st);  // out = g * s * (1 - s), s = the sigmoid's output
 int geglu_bwd(const float *x, const float *dy, float *dx, long long M, int inner, hipStream_t st);
 int transpose_scale(const float *W, int ldw, const float *gamma, float *Wt, int N, int K, hipStream_t st);  // Wt[k,n] = W[n,k] * gamma[n]
 int skinny_xwt(const float *X, long long M, int K, int ldx, const float *Wr, int r, float *T, hipStream_t st);  // T[M,r] = X Wr^T, Wr [r,K]

@@ -111,6 +111,33 @@ def test_output_head_conv_gradients(lib, cuda, case, head_key):
     print(f"\n[{case}] {len(names)} tensors ({n_head} head convolution tensors), worst scale-relative gradient error {worst:.2e}")
 
 
+@pytest.mark.parametrize("lora_type", ["none", "dvlora"])
+def test_out_sigmoid_gradients(lib, cuda, lora_type):
+    """--out_sigmoid with the VDA head (dpt_pyramid.py:97-101): every scale passes through a sigmoid after the downsampling chain.
+    lora_type none: only scratch.output_conv* trainable (--train_output_conv), the backward stops at the head; dvlora: LoRA factors too."""
+    from tests.golden.cases import VITS_SMALL_HEAD
+
+    kwargs = dict(VITS_SMALL_HEAD, image_shape=(42, 56), lora_type=lora_type, disable_conv_head=True, out_sigmoid=True)
+    model = endodav_amd.endodav(**kwargs, pretrained_path=None)
+    synth.fill_module_(model)
+    names = []
+    for n, p in model.named_parameters():
+        p.requires_grad = n.startswith("head.scratch.output_conv") or (".mlp.fc" in n and n.rsplit(".", 1)[-1] in ("lora_A", "lora_B"))
+        if p.requires_grad:
+            names.append(n)
+    assert len(names) == (6 if lora_type == "none" else 54)
+    x = torch.from_numpy(synth.synth_clip(1, 3, 42, 56, seed=2, kind="tissue"))
+    model = model.to(cuda).train()
+    gouts = upstream([(3, 1, h, w) for (h, w) in model.output_shapes()])
+    ref, out_ref = oracle_grads(model, kwargs, x, names, gouts)
+    hip, out = hip_grads(model, x, names, gouts, cuda)
+    for s in range(4):
+        a, b = out[("disp", s)].detach().cpu(), out_ref[("disp", s)].detach()
+        assert (a - b).abs().max().item() <= 5e-5 * b.abs().max().item()
+    worst = check(hip, ref)
+    print(f"\n[out_sigmoid, lora_type {lora_type}] {len(names)} tensors, worst scale-relative gradient error {worst:.2e}")
+
+
 @pytest.mark.parametrize("temporal", [False, True], ids=["spatial", "spatial+temporal"])
 def test_ssb_gradients(lib, cuda, temporal):
     """Linear_SSB (lora_A [in,1], lora_B [out,1]), the lora_type of the reference's scripts/train_video.sh, with and without

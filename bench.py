@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--clips", type=int, default=1, help="clips per GPU per step (a batch [B,T,...] through one forward)")
     ap.add_argument("--conv-head", action="store_true", help="the four HeadDepth heads instead of the VDA head (reference default; with --train "
                     "their convolutions are trainable next to the LoRA factors, endodav/layers.py:5-34)")
+    ap.add_argument("--lora", default="dvlora", choices=["none", "lora", "dvlora", "ssb"], help="lora_type (the reference's train_video*.sh use ssb)")
+    ap.add_argument("--temporal-lora", action="store_true", help="LoRA on ff.net.2 of the motion modules too (--temporal_lora)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with HIP events")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(16, cores): the box's CPU share)")
@@ -117,7 +119,8 @@ def main():
 
     kwargs = MODELS[args.encoder]
     T, S = args.T, args.image
-    model = endodav_amd.endodav(**kwargs, image_shape=(S, S), lora_type="dvlora", disable_conv_head=not args.conv_head).eval()
+    model = endodav_amd.endodav(**kwargs, image_shape=(S, S), lora_type=args.lora, temporal_lora=args.temporal_lora,
+                                disable_conv_head=not args.conv_head).eval()
     synth.fill_module_(model)
     model = model.to(dev)
     Bc = args.clips
@@ -210,7 +213,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"ViT-{args.encoder[-1].upper()} endodav (features {kwargs['features']}, out_channels {kwargs['out_channels']}, "
-                                   f"dvlora r=4, {'conv head' if args.conv_head else 'VDA head'}), {Bc} synthetic {S}x{S} T={T} clip(s) per GPU per step (BASELINE.json configs[1] shape), "
+                                   f"{args.lora} r=4, {'conv head' if args.conv_head else 'VDA head'}), {Bc} synthetic {S}x{S} T={T} clip(s) per GPU per step (BASELINE.json configs[1] shape), "
                                    "hash-initialised weights", "encoder": args.encoder, "T": T, "image": [S, S], "clips_per_gpu_per_step": Bc,
                        "parallelism": f"clip-sharded x{world}, no data-path collective"},
             "model_tflop_per_clip": round(GFLOP_PER_FRAME[args.encoder] * T / 1e3 * (S / 518.0) ** 2, 4),
@@ -268,7 +271,7 @@ def train_bench(args, model, x, dev, rank, world, kwargs, sync_all):
             "metric": f"fine-tune frames/sec ({S}x{S}, T={T} clip, LoRA factors trainable)", "value": round(frames / dt, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"ViT-{args.encoder[-1].upper()} endodav fine-tune step (dvlora r=4, {'conv head, conv_depth_* trainable' if args.conv_head else 'VDA head'}): forward + L1 stand-in loss + HIP "
+            "config": {"workload": f"ViT-{args.encoder[-1].upper()} endodav fine-tune step ({args.lora}{' + temporal_lora' if args.temporal_lora else ''} r=4, {'conv head, conv_depth_* trainable' if args.conv_head else 'VDA head'}): forward + L1 stand-in loss + HIP "
                                    f"backward + gradient all-reduce + AdamW, {args.clips} synthetic {S}x{S} T={T} clip(s) per GPU per step",
                        "encoder": args.encoder, "T": T, "image": [S, S], "clips_per_gpu_per_step": args.clips,
                        "parallelism": f"data-parallel x{world}: one all-reduce of {nred} gradient floats per step"},

@@ -204,14 +204,28 @@ __global__ __launch_bounds__(256) void tall_tn_partial_kernel(const float *__res
             part[((long long)blockIdx.y * N + n) * R + j] = (red[0][lane][j] + red[1][lane][j]) + (red[2][lane][j] + red[3][lane][j]);
     }
 }
-// out[n, j] = scale * (rowscale ? rowscale[n] : 1) * sum_s part[s, n, j]   (fixed order: deterministic)
+// out[n, j] = scale * (rowscale ? rowscale[n] : 1) * sum_s part[s, n, j].  A workgroup = 32 consecutive elements x 8 slices of the
+// split range; each thread adds its slice in split order, the slices are added in slice order: a fixed order, hence deterministic
+// (one thread per element walking all splits took 16 us per call on a chain of dependent loads).
 __global__ __launch_bounds__(256) void tall_tn_reduce_kernel(const float *__restrict__ part, int splits, int N, int R, float scale,
                                                              const float *__restrict__ rowscale, float *__restrict__ out) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= N * R) return;
+    __shared__ float red[8][32];
+    const int e = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + e;
     float s = 0.f;
-    for (int sp = 0; sp < splits; ++sp) s += part[(long long)sp * N * R + i];
-    out[i] = s * scale * (rowscale ? rowscale[i / R] : 1.f);
+    if (i < N * R) {
+        const int per = (splits + 7) / 8, s0 = slice * per, s1 = s0 + per < splits ? s0 + per : splits;
+#pragma unroll 8
+        for (int sp = s0; sp < s1; ++sp) s += part[(long long)sp * N * R + i];
+    }
+    red[slice][e] = s;
+    __syncthreads();
+    if (slice == 0 && i < N * R) {
+        float t = red[0][e];
+#pragma unroll
+        for (int k = 1; k < 8; ++k) t += red[k][e];
+        out[i] = t * scale * (rowscale ? rowscale[i / R] : 1.f);
+    }
 }
 
 // LoRA factor gradients from dBp [out, r] (= s dY^T (X A'^T)) and dApT [in, r] (= s X^T (dY B')), mylora/layers.py:148-157, 384-393.
@@ -780,7 +794,7 @@ int tall_tn(const float *Y, int ldy, const float *T, long long M, int N, int r, 
         default: hipLaunchKernelGGL(tall_tn_partial_kernel<8>, grid, block, 0, st, Y, ldy, T, M, N, part, rows_per_split); break;
     }
     EDV_LAUNCH_OK();
-    hipLaunchKernelGGL(tall_tn_reduce_kernel, dim3((N * r + 255) / 256), dim3(256), 0, st, part, splits, N, r, scale, rowscale, out);
+    hipLaunchKernelGGL(tall_tn_reduce_kernel, dim3((N * r + 31) / 32), dim3(256), 0, st, part, splits, N, r, scale, rowscale, out);
     EDV_LAUNCH_OK();
     return 0;
 }
@@ -839,7 +853,7 @@ int col_dot(const float *P, const float *Q, long long M, int N, const float *sca
     const int splits = (int)((M + rows_per_split - 1) / rows_per_split);
     hipLaunchKernelGGL(col_dot_partial_kernel, dim3((N + 63) / 64, splits), dim3(256), 0, st, P, Q, M, N, part, rows_per_split);
     EDV_LAUNCH_OK();
-    hipLaunchKernelGGL(tall_tn_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, st, part, splits, N, 1, 1.0f, scale, out);
+    hipLaunchKernelGGL(tall_tn_reduce_kernel, dim3((N + 31) / 32), dim3(256), 0, st, part, splits, N, 1, 1.0f, scale, out);
     EDV_LAUNCH_OK();
     return 0;
 }

@@ -1254,7 +1254,6 @@ struct Run {
         EDV_CHECK(!cfg.use_bn, "the fine-tune step with use_bn=True is not built (train-mode BatchNorm uses batch statistics)");
         EDV_CHECK(c->prepared, "edv_prepare has not run");
         EDV_CHECK(!cfg.use_clstoken, "training does not support use_clstoken");
-        EDV_CHECK(cfg.lora_type != EDV_LORA_DASH, "training supports lora_type none, lora, dvlora and ssb");
         const int *oc = cfg.out_channels;
         for (int i = 0; i < depth; ++i) {
             const std::string bp = "pretrained.blocks." + std::to_string(i);
@@ -1387,7 +1386,7 @@ struct Run {
         if (cfg.temporal_lora && cfg.lora_type != EDV_LORA_NONE && c->grad_temporal) {  // temporal LoRA on ff.net.2 (endodav.py:119-137)
             const float *ff2;
             EDV_TRY(saved(tg + "ff2", &ff2));
-            EDV_TRY(lora_step(tb + ".ff.net.2", ff2, 4 * C, dh, C, M, cfg.lora_rank, cfg.lora_type == EDV_LORA_LORA ? 2.0f : 1.0f, "", lora_ws, lora_ws_n));
+            EDV_TRY(lora_step(tb + ".ff.net.2", ff2, 4 * C, dh, C, M, cfg.lora_rank, (cfg.lora_type == EDV_LORA_LORA || cfg.lora_type == EDV_LORA_DASH) ? 2.0f : 1.0f, "", lora_ws, lora_ws_n));
         }
         EDV_TRY(dgemm(dh, M, C, tb + ".ff.net.2", 4 * C, t4));             // h3 = h2 + ff2 W2
         EDV_TRY(geglu_bwd(ff1, t4, t8, M, 4 * C, st));
@@ -1630,7 +1629,9 @@ struct Run {
         const size_t lws_n = lora_ws_n;
         lws = lora_ws;
         EDV_HIP(hipMemsetAsync(dxt, 0, (size_t)MT * D * sizeof(float), st));
-        const float lscale = cfg.lora_type == EDV_LORA_LORA ? 2.0f : 1.0f;  // lora_alpha / r (endodav.py:108-112)
+        // lora_alpha / r (endodav.py:108-117).  dash: the gradient of lora_A / lora_B is LoRA's in both phases -- past the warm-up the
+        // extra term U_top diag(lora_index) Vt_top is part of the folded (frozen) weight the input gradients already use
+        const float lscale = (cfg.lora_type == EDV_LORA_LORA || cfg.lora_type == EDV_LORA_DASH) ? 2.0f : 1.0f;
         const float *nw;
         EDV_TRY(param("pretrained.norm.weight", &nw));
         int tapj = 3;
@@ -1719,7 +1720,27 @@ struct Run {
             EDV_TRY(gradbuf(p + ".lora_V", (size_t)nout, &dV));
         }
         c->launches += 8;
-        return lora_grads(X, nin, G, nout, M, nin, nout, r, A, Bm, U, V, s, gam, lws, lws_n, dA, dB, dU, dV, st);
+        EDV_TRY(lora_grads(X, nin, G, nout, M, nin, nout, r, A, Bm, U, V, s, gam, lws, lws_n, dA, dB, dU, dV, st));
+        if (cfg.lora_type == EDV_LORA_DASH && cfg.dash_active) {
+            // DashLinear past its warm-up adds x (U_top diag(idx) Vt_top)^T (mylora/layers.py:580-582) and frees lora_index:
+            // d idx[j] = sum_m ((G * gamma) U_top)[m, j] (x Vt_top^T)[m, j] -- two skinny products and a column dot
+            const float *Ut, *Vt;
+            EDV_TRY(param(p + ".weight_u_top", &Ut));
+            EDV_TRY(param(p + ".weight_vt_top", &Vt));
+            const int ri = (int)c->params[p + ".lora_index"].shape[0];
+            float *utg, *t1, *t2, *part, *didx;
+            EDV_TRY(wsbuf("g.dash.utg", (size_t)ri * nout, &utg));
+            EDV_TRY(wsbuf("g.dash.t1", (size_t)M * ri, &t1));
+            EDV_TRY(wsbuf("g.dash.t2", (size_t)M * ri, &t2));
+            EDV_TRY(wsbuf("g.dash.part", (size_t)TALL_SPLITS * ri, &part));
+            EDV_TRY(gradbuf(p + ".lora_index", (size_t)ri, &didx));
+            EDV_TRY(transpose_scale(Ut, ri, gam, utg, nout, ri, st));  // [nout, ri] -> [ri, nout], rows scaled by gamma
+            EDV_TRY(skinny_xwt(G, M, nout, nout, utg, ri, t1, st));
+            EDV_TRY(skinny_xwt(X, M, nin, nin, Vt, ri, t2, st));
+            EDV_TRY(col_dot(t1, t2, M, ri, nullptr, part, didx, st));
+            c->launches += 5;
+        }
+        return 0;
     }
 };
 
@@ -1819,7 +1840,6 @@ int edv_forward(edv_ctx *ctx, const float *x_dev, int32_t B, int32_t T, int32_t 
     if (ctx->train) {
         const edv_config &c = ctx->cfg;
         EDV_CHECK(!c.use_clstoken, "training does not support use_clstoken");
-        EDV_CHECK(c.lora_type != EDV_LORA_DASH, "training supports lora_type none, lora, dvlora and ssb");
         EDV_CHECK(!ctx->capture, "stage capture and training are exclusive");
     }
     Run r(ctx, (hipStream_t)stream);

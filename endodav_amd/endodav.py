@@ -343,7 +343,7 @@ class _Head(_Holder):
 
 def _is_lora_factor(name: str) -> bool:
     """Factors of the linears edv_refresh_lora re-folds: mlp.fc1/fc2 of the encoder blocks, ff.net.2 of the motion modules."""
-    return (".mlp.fc" in name or ".ff.net.2." in name) and name.rsplit(".", 1)[-1] in ("lora_A", "lora_B", "lora_U", "lora_V")
+    return (".mlp.fc" in name or ".ff.net.2." in name) and name.rsplit(".", 1)[-1] in ("lora_A", "lora_B", "lora_U", "lora_V", "lora_index")
 
 
 def _is_head_conv(name: str) -> bool:
@@ -514,7 +514,7 @@ class endodav(nn.Module):
         if self.pe == "rope":  # the rotary tables are not state (motion_module.py:221-225) but the engine reads them like weights
             sd.update({k: v for k, v in self.named_buffers() if k.endswith(".freqs_cis")})
         sig = tuple((k, v.data_ptr(), v._version) for k, v in sd.items())
-        if sig != nat.sig and nat.sig is not None and len(sig) == len(nat.sig) and self.lora_type != "dash" and all(
+        if sig != nat.sig and nat.sig is not None and len(sig) == len(nat.sig) and all(
                 a[:2] == b[:2] and (a[2] == b[2] or _is_lora_factor(a[0]) or _is_head_conv(a[0]) or ".residual_." in a[0]) for a, b in zip(sig, nat.sig)):
             # the fine-tune loop: same tensors, only trainable ones written (optimizer.step) -> re-fold / re-pack those only
             _lib.check(lib.edv_refresh_lora(C.c_void_p(nat.handle), C.c_void_p(_lib.stream_ptr(device))), "edv_refresh_lora")
@@ -622,8 +622,8 @@ class endodav(nn.Module):
             raise NotImplementedError(f"libendodav_hip has no gradient for {bad[:4]}{' ...' if len(bad) > 4 else ''}: the HIP backward covers the LoRA "
                                       "factors of the encoder MLPs (and, with temporal_lora, of ff.net.2 in the motion modules), the residual bottleneck "
                                       "blocks residual_* and the output-head convolutions conv_depth_* / scratch.output_conv* (SURVEY.md §8f rank 3)")
-        if any(_is_lora_factor(n) for n in names) and self.lora_type not in ("lora", "dvlora", "ssb"):
-            raise NotImplementedError(f"the HIP backward supports lora_type 'lora', 'dvlora' and 'ssb', not {self.lora_type!r}")
+        if any(_is_lora_factor(n) for n in names) and self.lora_type not in ("lora", "dvlora", "ssb", "dash"):
+            raise NotImplementedError(f"the HIP backward supports lora_type 'lora', 'dvlora', 'ssb' and 'dash', not {self.lora_type!r}")
         return names
 
     # ---- debug taps for the per-stage parity tests --------------------------------------------

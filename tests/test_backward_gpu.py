@@ -111,6 +111,42 @@ def test_output_head_conv_gradients(lib, cuda, case, head_key):
     print(f"\n[{case}] {len(names)} tensors ({n_head} head convolution tensors), worst scale-relative gradient error {worst:.2e}")
 
 
+@pytest.mark.parametrize("active", [False, True], ids=["warm_up", "active"])
+def test_dash_gradients(lib, cuda, active):
+    """DashLinear (mylora/layers.py:497-583): plain LoRA (lora_alpha = 2r) during its 100-call warm-up; from call 101 on the layer adds
+    x (U_top diag(lora_index) Vt_top)^T and frees lora_index.  lora_A / lora_B keep LoRA's gradient, lora_index gets its own."""
+    case = "micro_dash_active" if active else "micro_dash"
+    model, kwargs, shape, kind, _ = build_model(case)
+    x = case_input(case)
+    model = model.to(cuda).train()
+    if active:
+        with torch.no_grad():
+            model(x.to(cuda))  # call 101: direction selection, lora_index freed
+        assert all(m.lora_index.requires_grad for m in model._dash_layers())
+    names = []
+    for n, p in model.named_parameters():
+        p.requires_grad = ".mlp.fc" in n and n.rsplit(".", 1)[-1] in (("lora_A", "lora_B", "lora_index") if active else ("lora_A", "lora_B"))
+        if p.requires_grad:
+            names.append(n)
+    assert len(names) == (72 if active else 48)
+    BT = shape[0] * shape[1]
+    gouts = upstream([(BT, 1, h, w) for (h, w) in model.output_shapes()])
+    sd = {k: (v.detach().cpu().clone()) for k, v in model.state_dict().items()}
+    for n in names:
+        sd[n].requires_grad_(True)
+    out_ref = orc.forward(sd, x, oracle_config(kwargs, dash_active=active))
+    loss = sum((out_ref[("disp", s)] * gouts[s]).sum() for s in range(4))
+    ref = dict(zip(names, torch.autograd.grad(loss, [sd[n] for n in names])))
+    calls = model._dash_calls
+    hip, out = hip_grads(model, x, names, gouts, cuda)
+    assert model._dash_calls == calls + 1
+    for s in range(4):
+        a, b = out[("disp", s)].detach().cpu(), out_ref[("disp", s)].detach()
+        assert (a - b).abs().max().item() <= 5e-5 * b.abs().max().item()
+    worst = check(hip, ref)
+    print(f"\n[dash {'active' if active else 'warm-up'}] {len(names)} tensors, worst scale-relative gradient error {worst:.2e}")
+
+
 @pytest.mark.parametrize("lora_type", ["none", "dvlora"])
 def test_out_sigmoid_gradients(lib, cuda, lora_type):
     """--out_sigmoid with the VDA head (dpt_pyramid.py:97-101): every scale passes through a sigmoid after the downsampling chain.

@@ -163,8 +163,11 @@ def main():
     # bracketed linear launches itself (2 M N K and A, W, C (+ residual) once).
     roofline = roofline_attn = None
     if not args.no_kernel_events:
-        n_l, ms_l = model.profile_read("linear")
-        fl_l, by_l = model.profile_work("linear")
+        n_h, ms_h = model.profile_read("linear")          # patch embed + DPT head
+        fl_h, by_h = model.profile_work("linear")
+        n_e, ms_e = model.profile_read("linear_encoder")  # qkv / proj / fc1 / fc2 of the encoder blocks
+        fl_e, by_e = model.profile_work("linear_encoder")
+        n_l, ms_l, fl_l, by_l = n_h + n_e, ms_h + ms_e, fl_h + fl_e, by_h + by_e
         if n_l > 0 and ms_l > 0:
             achieved = fl_l / (ms_l * 1e-3) / 1e12
             roofline = {"kernel": "gemm_dma_kernel (every F.linear / 1x1 conv of the step: qkv, proj, fc1, fc2 of the 12 blocks + the head's)",
@@ -173,6 +176,11 @@ def main():
                         "traffic_unit": "bytes per launch, mean over the step's launches (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_gemm_traffic.json)",
                         "algorithmic_bytes_per_launch": round(by_l / n_l, 1), "launches": n_l, "avg_launch_ms": round(ms_l / n_l, 4),
                         "flop_per_launch": round(fl_l / n_l, 1), "peak_dtype": "f32 MFMA (v_mfma_f32_32x32x2_f32), dense"}
+            if n_e > 0 and ms_e > 0:  # the same kernel on the encoder's four shapes only (the head's small GEMMs are HBM- / launch-bound)
+                ach_e = fl_e / (ms_e * 1e-3) / 1e12
+                roofline["encoder_launches"] = {"achieved": round(ach_e, 2), "frac": round(ach_e / PEAK_F32_MFMA_TFLOPS, 4), "launches": n_e,
+                                                "avg_launch_ms": round(ms_e / n_e, 4), "flop_per_launch": round(fl_e / n_e, 1),
+                                                "share_of_linear_flop": round(fl_e / fl_l, 4)}
         n, ms = model.profile_read("attn_spatial")
         D, depth, heads = DIMS[args.encoder]
         ntok = (S // 14) ** 2 + 1

@@ -118,7 +118,9 @@ SIGNATURES = {
 }
 
 
-KERNEL_CLASSES = {"linear": 0, "conv3x3": 1, "attn_spatial": 2, "attn_temporal": 3, "layernorm": 4, "other": 5}
+# "linear_encoder" (the F.linear launches of the encoder blocks) is recorded whenever "linear" is enabled and read separately;
+# "linear" then holds the remaining F.linear / 1x1-conv launches (patch embed, DPT head)
+KERNEL_CLASSES = {"linear": 0, "conv3x3": 1, "attn_spatial": 2, "attn_temporal": 3, "layernorm": 4, "other": 5, "linear_encoder": 6}
 
 
 class EdvError(RuntimeError):

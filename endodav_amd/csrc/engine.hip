@@ -43,7 +43,9 @@ struct Buf {
 };
 
 // kernel classes for the optional HIP-event bracketing (edv_profile_enable / edv_profile_read)
-enum { KC_LINEAR = 0, KC_CONV3 = 1, KC_ATTN_SPATIAL = 2, KC_ATTN_TEMPORAL = 3, KC_NORM = 4, KC_OTHER = 5, KC_COUNT = 6 };
+// KC_LINEAR_ENC: the F.linear launches of the encoder blocks (qkv, proj, fc1, fc2: 96 % of the dense-GEMM work), a sub-class bracketed
+// with the same mask bit as KC_LINEAR and reported separately (the head's small GEMMs are HBM- and launch-bound, not MFMA-bound)
+enum { KC_LINEAR = 0, KC_CONV3 = 1, KC_ATTN_SPATIAL = 2, KC_ATTN_TEMPORAL = 3, KC_NORM = 4, KC_OTHER = 5, KC_LINEAR_ENC = 6, KC_COUNT = 7 };
 struct EvPool {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     size_t used = 0;
@@ -53,8 +55,8 @@ struct edv_ctx {
     edv_config cfg{};
     unsigned prof_mask = 0;
     EvPool prof[KC_COUNT];
-    double prof_flops[KC_COUNT] = {0, 0, 0, 0, 0, 0};  // algorithmic work of the bracketed launches (edv_profile_work)
-    double prof_bytes[KC_COUNT] = {0, 0, 0, 0, 0, 0};
+    double prof_flops[KC_COUNT] = {0, 0, 0, 0, 0, 0, 0};  // algorithmic work of the bracketed launches (edv_profile_work)
+    double prof_bytes[KC_COUNT] = {0, 0, 0, 0, 0, 0, 0};
     int enc_streams = 0;                      // 0: automatic (2 for small clips); n >= 1: that many frame groups on internal streams
     int enc_streams_initial = 0;              // what EDV_ENC_STREAMS asked for at edv_create (edv_set_encoder_streams(-1) restores it)
     hipStream_t sub[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -109,7 +111,7 @@ struct Bracket {
     hipEvent_t stop = nullptr;
     hipStream_t st;
     Bracket(edv_ctx *c, int cls, hipStream_t s) : st(s) {
-        if (!(c->prof_mask & (1u << cls))) return;
+        if (!(c->prof_mask & (1u << (cls == KC_LINEAR_ENC ? KC_LINEAR : cls)))) return;  // the sub-class shares its parent's mask bit
         EvPool &p = c->prof[cls];
         if (p.used == p.ev.size()) {
             hipEvent_t a, b;
@@ -164,6 +166,7 @@ struct Run {
     }
 
     // ---- op wrappers ----------------------------------------------------------------------
+    bool in_encoder = false;      // linear() is being called from the encoder block loop (profiling sub-class KC_LINEAR_ENC)
     bool stagger_record = false;  // encoder_range records ev_x[5] after block 0's qkv GEMM (start signal for the next frame group)
     float *skws = nullptr;  // stream-K split workspace of the stream this Run is enqueueing on
     size_t skws_floats = 0;
@@ -178,11 +181,12 @@ struct Run {
         g.A = A; g.lda = K; g.W = W; g.ldw = K; g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K;
         g.bias = bias; g.act = act; g.gamma = gamma; g.R1 = R1; g.ldr1 = N;
         c->launches++;
+        const int cls = in_encoder ? KC_LINEAR_ENC : KC_LINEAR;
         if (c->prof_mask & (1u << KC_LINEAR)) {  // 2 M N K; A, W read once, C written once (+ the residual read)
-            c->prof_flops[KC_LINEAR] += 2.0 * (double)M * N * K;
-            c->prof_bytes[KC_LINEAR] += 4.0 * ((double)M * K + (double)N * K + (double)M * N * (R1 ? 2 : 1));
+            c->prof_flops[cls] += 2.0 * (double)M * N * K;
+            c->prof_bytes[cls] += 4.0 * ((double)M * K + (double)N * K + (double)M * N * (R1 ? 2 : 1));
         }
-        Bracket b_(c, KC_LINEAR, st);
+        Bracket b_(c, cls, st);
         return gemm_ws(g);
     }
     int conv3(const float *x, int H, int W, int Cin, const float *wp, const float *bias, int Cout, int stride, float *y, bool pre_relu,
@@ -806,6 +810,7 @@ struct Run {
         EDV_TRY(snapshot("tokens", xt, (size_t)MT * D));
 
         int tapj = 0;
+        in_encoder = true;
         for (int i = 0; i < depth; ++i) {
             const std::string bp = "pretrained.blocks." + std::to_string(i);
             const float *w, *b, *gam;
@@ -864,6 +869,7 @@ struct Run {
                 ++tapj;
             }
         }
+        in_encoder = false;
         EDV_CHECK(tapj == 4, "taps must be increasing block indices < depth");
         return 0;
     }

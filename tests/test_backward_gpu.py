@@ -65,7 +65,8 @@ def check(hip, ref, tol=2e-4):
     return worst
 
 
-@pytest.mark.parametrize("case", ["micro_vda_dvlora", "micro_vda_lora_b2", "micro_t1", "micro_vda_temporal_lora", "micro_rope"])
+@pytest.mark.parametrize("case", ["micro_vda_dvlora", "micro_vda_lora_b2", "micro_t1", "micro_vda_temporal_lora", "micro_rope", "micro_vda_nocls", "micro_vitl",
+                                  "micro_resize_in"])
 def test_lora_gradients_match_oracle_autograd(lib, cuda, case):
     model, kwargs, shape, kind, _ = build_model(case)
     x = case_input(case)

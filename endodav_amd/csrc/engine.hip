@@ -1013,7 +1013,17 @@ struct Run {
                 g2.A = tap[j]; g2.lda = D; g2.W = rw; g2.ldw = 2 * D; g2.C = readout; g2.ldc = D; g2.M = MP; g2.N = D; g2.K = D;
                 g2.P1 = fbias; g2.ldp1 = D; g2.act = ACT_GELU;
                 g2.p1_map = RowMap{P0, 1, 0, 0};  // inner 0: one bias row per frame
-                EDV_TRY(gemm_ws(g2));
+                if (c->train) {  // keep the pre-activation of every level; GELU from the stored fp32 value (same values as the fused epilogue)
+                    float *pre;
+                    EDV_TRY(wsbuf("ro" + std::to_string(j) + ".pre", (size_t)MP * D, &pre));
+                    g2.C = pre;
+                    g2.act = ACT_NONE;
+                    EDV_TRY(gemm_ws(g2));
+                    EDV_TRY(ew_bwd(pre, nullptr, nullptr, readout, MP * D, 3, st));
+                    c->launches++;
+                } else {
+                    EDV_TRY(gemm_ws(g2));
+                }
                 c->launches += 2;
                 src = readout;
                 c->stages["tapcls" + std::to_string(j)] = {tapcls[j], (size_t)F * D};
@@ -1259,7 +1269,6 @@ struct Run {
     int prepare_train() {
         EDV_CHECK(!cfg.use_bn, "the fine-tune step with use_bn=True is not built (train-mode BatchNorm uses batch statistics)");
         EDV_CHECK(c->prepared, "edv_prepare has not run");
-        EDV_CHECK(!cfg.use_clstoken, "training does not support use_clstoken");
         const int *oc = cfg.out_channels;
         for (int i = 0; i < depth; ++i) {
             const std::string bp = "pretrained.blocks." + std::to_string(i);
@@ -1279,6 +1288,14 @@ struct Run {
                 EDV_TRY(make_b_c3(rp + ".conv2"));
             }
         for (int j = 0; j < 4; ++j) EDV_TRY(make_t_lin("head.projects." + std::to_string(j)));
+        if (cfg.use_clstoken)
+            for (int j = 0; j < 4; ++j) {  // readout_projects[j].0.weight = [W1 | W2] (dpt.py:92-98): both halves, transposed
+                const std::string rp = "head.readout_projects." + std::to_string(j) + ".0";
+                const float *rw;
+                EDV_TRY(param(rp + ".weight", &rw, 2));
+                EDV_TRY(make_t(rp + ".w1", rw, 2 * D, D, D, nullptr));
+                EDV_TRY(make_t(rp + ".w2", rw + D, 2 * D, D, D, nullptr));
+            }
         for (int j = 0; j < 2; ++j) {
             const std::string rp = "head.resize_layers." + std::to_string(j);
             const int s2 = (j == 0 ? 16 : 4);
@@ -1579,7 +1596,7 @@ struct Run {
         EDV_TRY(fusion_bwd(4, d_p4, r[4], nullptr, h4, w4, h3, w3, d_r[4], nullptr));
 
         // ---------------- layerN_rn, motion modules 0/1, reassemble, projects -> gradient of the four taps ----------
-        float *d_l[5], *d_pj, *d_tap[4];
+        float *d_l[5], *d_pj, *d_tap[4], *d_tapcls[4] = {nullptr, nullptr, nullptr, nullptr};
         const int hs_[5] = {0, h1, h2, h3, h4}, ws_[5] = {0, w1, w2, w3, w4};
         for (int j = 1; j <= 4; ++j) {
             EDV_TRY(wsbuf("g.l" + std::to_string(j), (size_t)F * hs_[j] * ws_[j] * oc[j - 1], &d_l[j]));
@@ -1617,6 +1634,23 @@ struct Run {
                 EDV_TRY(dconv3(z, ph, pw, oc[3], "head.resize_layers.3", oc[3], d_pj));
             }
             EDV_TRY(dgemm(src, MP, oc[j], "head.projects." + std::to_string(j), D, d_tap[j]));
+            if (cfg.use_clstoken) {
+                // projects[j] read GELU(W1 tap + (W2 cls + b)) (dpt_pyramid.py:54-57): through the GELU, W1 back to the patch rows,
+                // the per-frame sums of the pre-activation gradient through W2 back to the frame's cls row of the tap
+                const std::string rp = "head.readout_projects." + std::to_string(j) + ".0";
+                const float *pre;
+                float *dpre, *dfb, *part;
+                EDV_TRY(saved("ro" + std::to_string(j) + ".pre", &pre));
+                EDV_TRY(wsbuf("g.ro.dpre", (size_t)MP * D, &dpre));
+                EDV_TRY(wsbuf("g.ro.dfb", (size_t)F * D, &dfb));
+                EDV_TRY(wsbuf("g.ro.part", (size_t)TALL_SPLITS * D, &part));
+                EDV_TRY(wsbuf("g.tapcls" + std::to_string(j), (size_t)F * D, &d_tapcls[j]));
+                EDV_TRY(ew_bwd(d_tap[j], pre, nullptr, dpre, MP * D, 1, st));
+                for (int f = 0; f < F; ++f) EDV_TRY(col_dot(dpre + (size_t)f * P0 * D, nullptr, P0, D, nullptr, part, dfb + (size_t)f * D, st));
+                EDV_TRY(dgemm(dpre, MP, D, rp + ".w1", D, d_tap[j]));
+                EDV_TRY(dgemm(dfb, F, D, rp + ".w2", D, d_tapcls[j]));
+                c->launches += 3 + 2 * F;
+            }
         }
         c->launches += 12;
 
@@ -1655,6 +1689,8 @@ struct Run {
             EDV_TRY(saved("t.hid" + is, &hid));
             if (tapj >= 0 && cfg.taps[tapj] == i) {  // tap = norm(x_out) on the patch rows (vision_transformer.py:317-321)
                 EDV_TRY(layernorm_bwd(x_out, RowMap{P0, ntok, c0}, nw, d_tap[tapj], identity_map(), dxt, RowMap{P0, ntok, c0}, MP, D, 1e-6f, true, st));
+                if (cfg.use_clstoken)  // the readout's class-token input: the final norm of token 0 of every frame (vision_transformer.py:322-324)
+                    EDV_TRY(layernorm_bwd(x_out, RowMap{1, ntok, 0}, nw, d_tapcls[tapj], identity_map(), dxt, RowMap{1, ntok, 0}, F, D, 1e-6f, true, st));
                 --tapj;
             }
             if (cfg.residual_mask & (1u << i)) EDV_TRY(res_bottleneck_bwd(i, dxt));  // x_out = x' + residual_(x' patch rows)
@@ -1845,7 +1881,6 @@ int edv_forward(edv_ctx *ctx, const float *x_dev, int32_t B, int32_t T, int32_t 
     for (int k = 0; k < 4; ++k) EDV_CHECK(disp_dev[k], "null output");
     if (ctx->train) {
         const edv_config &c = ctx->cfg;
-        EDV_CHECK(!c.use_clstoken, "training does not support use_clstoken");
         EDV_CHECK(!ctx->capture, "stage capture and training are exclusive");
     }
     Run r(ctx, (hipStream_t)stream);

@@ -66,7 +66,7 @@ def check(hip, ref, tol=2e-4):
 
 
 @pytest.mark.parametrize("case", ["micro_vda_dvlora", "micro_vda_lora_b2", "micro_t1", "micro_vda_temporal_lora", "micro_rope", "micro_vda_nocls", "micro_vitl",
-                                  "micro_resize_in"])
+                                  "micro_resize_in", "micro_clstoken"])
 def test_lora_gradients_match_oracle_autograd(lib, cuda, case):
     model, kwargs, shape, kind, _ = build_model(case)
     x = case_input(case)
@@ -85,8 +85,8 @@ def test_lora_gradients_match_oracle_autograd(lib, cuda, case):
 
 
 @pytest.mark.parametrize("case,head_key", [("micro_conv_dvlora", "head.conv_depth_"), ("micro_conv_invsig_ssb", "head.conv_depth_"),
-                                           ("micro_vda_dvlora", "head.scratch.output_conv")],
-                         ids=["conv_head", "conv_head_inv_sigmoid_ssb", "vda_train_output_conv"])
+                                           ("micro_vda_dvlora", "head.scratch.output_conv"), ("micro_clstoken_nocls", "head.conv_depth_")],
+                         ids=["conv_head", "conv_head_inv_sigmoid_ssb", "vda_train_output_conv", "conv_head_use_clstoken_no_cls_token"])
 def test_output_head_conv_gradients(lib, cuda, case, head_key):
     """The reference's default options leave the four HeadDepth heads trainable next to the LoRA factors (endodav/layers.py:5-34:
     names containing conv_depth_), and --train_output_conv does the same for scratch.output_conv* of the VDA head: weight and bias
@@ -103,13 +103,15 @@ def test_output_head_conv_gradients(lib, cuda, case, head_key):
     model = model.to(cuda).train()
     BT = shape[0] * shape[1]
     gouts = upstream([(BT, 1, h, w) for (h, w) in model.output_shapes()])
-    ref, out_ref = oracle_grads(model, kwargs, x, names, gouts)
+    # fp64 graph: in the use_clstoken case the fp32 CPU oracle itself sits 3e-4 .. 6e-4 from it (one ReLU mask at an fp32-noise zero
+    # crossing, scratch/dbg_clstoken_grad.py) while the HIP gradients are within 1e-5
+    ref, out_ref = oracle_grads(model, kwargs, x, names, gouts, torch.float64)
     hip, out = hip_grads(model, x, names, gouts, cuda)
     for s in range(4):
-        a, b = out[("disp", s)].detach().cpu(), out_ref[("disp", s)].detach()
+        a, b = out[("disp", s)].detach().cpu().double(), out_ref[("disp", s)].detach()
         assert (a - b).abs().max().item() <= 5e-5 * b.abs().max().item()
     worst = check(hip, ref)
-    print(f"\n[{case}] {len(names)} tensors ({n_head} head convolution tensors), worst scale-relative gradient error {worst:.2e}")
+    print(f"\n[{case}] {len(names)} tensors ({n_head} head convolution tensors), worst scale-relative gradient error vs the fp64 graph {worst:.2e}")
 
 
 @pytest.mark.parametrize("active", [False, True], ids=["warm_up", "active"])

@@ -166,6 +166,7 @@ struct Run {
     }
 
     // ---- op wrappers ----------------------------------------------------------------------
+    int enc_F = 0, enc_f0 = 0;    // all frames of the clip / first frame of the group encoder_range is working on (training buffers hold all frames)
     bool in_encoder = false;      // linear() is being called from the encoder block loop (profiling sub-class KC_LINEAR_ENC)
     bool stagger_record = false;  // encoder_range records ev_x[5] after block 0's qkv GEMM (start signal for the next frame group)
     float *skws = nullptr;  // stream-K split workspace of the stream this Run is enqueueing on
@@ -643,14 +644,14 @@ struct Run {
         const int Cb = D / 8;
         const long long MP = (long long)F * P0;
         float *xp, *t1a, *ln1, *a1, *t1b, *ln2, *a2, *t3;
-        EDV_TRY(wsbuf(tg + "xp", (size_t)MP * D, &xp));
-        EDV_TRY(wsbuf(tg + "t1a", (size_t)MP * Cb, &t1a));
-        EDV_TRY(wsbuf(tg + "ln1", (size_t)MP * Cb, &ln1));
-        EDV_TRY(wsbuf(tg + "a1", (size_t)MP * Cb, &a1));
-        EDV_TRY(wsbuf(tg + "t1b", (size_t)MP * Cb, &t1b));
-        EDV_TRY(wsbuf(tg + "ln2", (size_t)MP * Cb, &ln2));
-        EDV_TRY(wsbuf(tg + "a2", (size_t)MP * Cb, &a2));
-        EDV_TRY(wsbuf(tg + "t3", (size_t)MP * D, &t3));
+        EDV_TRY(trainbuf(tg + "xp", (size_t)P0 * D, &xp));
+        EDV_TRY(trainbuf(tg + "t1a", (size_t)P0 * Cb, &t1a));
+        EDV_TRY(trainbuf(tg + "ln1", (size_t)P0 * Cb, &ln1));
+        EDV_TRY(trainbuf(tg + "a1", (size_t)P0 * Cb, &a1));
+        EDV_TRY(trainbuf(tg + "t1b", (size_t)P0 * Cb, &t1b));
+        EDV_TRY(trainbuf(tg + "ln2", (size_t)P0 * Cb, &ln2));
+        EDV_TRY(trainbuf(tg + "a2", (size_t)P0 * Cb, &a2));
+        EDV_TRY(trainbuf(tg + "t3", (size_t)P0 * D, &t3));
         for (int f = 0; f < F; ++f)  // the patch rows of the residual stream, compact (block.py:146: .clone())
             EDV_TRY(copy_f32(xt + ((size_t)f * ntok + c0) * D, xp + (size_t)f * P0 * D, (long long)P0 * D, st));
         const float *w, *nw, *nb;
@@ -770,12 +771,20 @@ struct Run {
         for (int k = 0; k < 6; ++k) EDV_HIP(hipEventCreateWithFlags(&c->ev_x[k], hipEventDisableTiming));
         return 0;
     }
+    // a kept activation with `per_frame` floats per frame: sized for every frame of the clip, returned at this frame group's offset
+    int trainbuf(const std::string &name, size_t per_frame, float **out) {
+        float *base;
+        EDV_TRY(wsbuf(name, (size_t)enc_F * per_frame, &base));
+        *out = base + (size_t)enc_f0 * per_frame;
+        return 0;
+    }
     // encoder on frames [f0, f0 + nf) enqueued on stream s (vision_transformer.py:279-289 + :317-321)
     int encoder_range(const EncBufs &eb, const float *x, int f0, int nf, int H, int W, hipStream_t s, int lane = 0) {
         st = s;
         skws = eb.skws ? eb.skws + (size_t)lane * eb.skws_each : nullptr;
         skws_floats = eb.skws_each;
         F = nf;
+        enc_f0 = f0;
         const long long MT = (long long)nf * ntok;
         float *cols = eb.cols + (size_t)f0 * P0 * 588, *xt = eb.xt + (size_t)f0 * ntok * D, *xn = eb.xn + (size_t)f0 * ntok * D;
         float *qkv = eb.qkv + (size_t)f0 * ntok * 3 * D, *att = eb.att + (size_t)f0 * ntok * D, *hid = eb.hid + (size_t)f0 * ntok * 4 * D;
@@ -786,7 +795,7 @@ struct Run {
         }
         const float *pos = eb.pos;
         rb_suffix = "." + std::to_string(f0);
-        if (c->train) EDV_TRY(wsbuf("t.x.0", (size_t)MT * D, &xt));  // block i reads t.x.i and writes t.xmid.i, t.x.(i+1)
+        if (c->train) EDV_TRY(trainbuf("t.x.0", (size_t)ntok * D, &xt));  // block i reads t.x.i and writes t.xmid.i, t.x.(i+1)
         EDV_TRY(patchify(x + (size_t)f0 * 3 * H * W, cols, F, H, W, cfg.image_h, cfg.image_w, st));
         c->launches++;
         {
@@ -820,14 +829,14 @@ struct Run {
             if (c->train) {
                 const std::string is = "." + std::to_string(i);
                 x_in = xt;
-                EDV_TRY(wsbuf("t.xmid" + is, (size_t)MT * D, &x_mid));
-                EDV_TRY(wsbuf("t.x." + std::to_string(i + 1), (size_t)MT * D, &x_out));
-                EDV_TRY(wsbuf("t.xn2" + is, (size_t)MT * D, &xn2));
-                EDV_TRY(wsbuf("t.qkv" + is, (size_t)MT * 3 * D, &qkv));
-                EDV_TRY(wsbuf("t.att" + is, (size_t)MT * D, &att));
-                EDV_TRY(wsbuf("t.lse" + is, (size_t)F * heads * ntok, &lse));
-                EDV_TRY(wsbuf("t.pre" + is, (size_t)MT * 4 * D, &pre));
-                EDV_TRY(wsbuf("t.hid" + is, (size_t)MT * 4 * D, &hid));
+                EDV_TRY(trainbuf("t.xmid" + is, (size_t)ntok * D, &x_mid));
+                EDV_TRY(trainbuf("t.x." + std::to_string(i + 1), (size_t)ntok * D, &x_out));
+                EDV_TRY(trainbuf("t.xn2" + is, (size_t)ntok * D, &xn2));
+                EDV_TRY(trainbuf("t.qkv" + is, (size_t)ntok * 3 * D, &qkv));
+                EDV_TRY(trainbuf("t.att" + is, (size_t)ntok * D, &att));
+                EDV_TRY(trainbuf("t.lse" + is, (size_t)heads * ntok, &lse));
+                EDV_TRY(trainbuf("t.pre" + is, (size_t)ntok * 4 * D, &pre));
+                EDV_TRY(trainbuf("t.hid" + is, (size_t)ntok * 4 * D, &hid));
             }
             EDV_TRY(ln(x_in, identity_map(), bp + ".norm1", xn, MT, D, 1e-6f));
             EDV_TRY(param(bp + ".attn.qkv.weight", &w));
@@ -908,7 +917,11 @@ struct Run {
         // ViT-S T=4 +2.7 %, T=8 +4.8 %, T=16 +2.4 %, T=32 +1.3 %; ViT-B T=16 +-0; ViT-L T=32 -1.3 % (profiles/r01_gemm_tile_sweep.txt).
         int want = c->enc_streams;
         if (want <= 0) want = (MT * (long long)D <= 17000000ll) ? 2 : 1;
+        // Not while training: the kept activations are laid out per frame (trainbuf), so two groups work, but they measure slower
+        // there (ViT-S T=8 243 vs 257 frames/s, ViT-B T=16 224^2 506 vs 539, ssb T=16 907 vs 1040: the training forward's extra
+        // stores and unfused GELU leave less idle issue time to fill).
         int nstreams = (want > 1 && !c->capture && !c->train) ? (want > 4 ? 4 : want) : 1;
+        enc_F = F;
         if (nstreams > F) nstreams = F;
         size_t attws_each = 0;  // the largest split workspace any stream's share of the frames needs
         for (int h = 0, f0 = 0; h < nstreams; ++h) {

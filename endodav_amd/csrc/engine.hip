@@ -935,12 +935,12 @@ struct Run {
         // Stream-K for the dense GEMMs (gemm_dma.hip): the last partial round of output tiles is split along K over the resident
         // workgroups and merged in-kernel by the last piece to arrive.  One workspace region per stream that launches GEMMs
         // concurrently: the encoder's frame-group streams, and the head's caller / internal stream pair (regions 0 and 1).
-        // Opt-in (EDV_GEMM_STREAMK=1): in isolation the split wins 3-17 % on the deep-K GEMMs (fc2 at T=8: 137 -> 122 us with
-        // warm clocks), but inside the forward the same launches measure 138 vs 134 us by rocprofv3 and the step is within
-        // +-0.5 % either way on ViT-S T=4/8/16, ViT-B T=8/16 and the fine-tune step (profiles/r01_gemm_tile_sweep.txt).
+        // It applies to deep tiles only (K >= 768, grids under five rounds: gemm_dma.hip).  On by default: fc2 at T=8 138 -> 121 us,
+        // ViT-B fc2 at T=8 472 -> 430 us; end to end +0.1 .. +0.7 % on ViT-S T=4/8/16, ViT-B T=8/16 and the fine-tune step
+        // (profiles/r01_gemm_tile_sweep.txt).  EDV_GEMM_STREAMK=0 restores one workgroup per tile.
         static const bool gemm_streamk = [] {
             const char *e = getenv("EDV_GEMM_STREAMK");
-            return e && atoi(e) != 0;
+            return !(e && atoi(e) == 0);
         }();
         const size_t skws_each = gemm_streamk ? gemm_workspace() : 0;
         const int skws_regions = nstreams > 2 ? nstreams : 2;
@@ -1490,8 +1490,12 @@ struct Run {
         const int *oc = cfg.out_channels;
         const int h1 = 4 * ph, w1 = 4 * pw, h2 = 2 * ph, w2 = 2 * pw, h3 = ph, w3 = pw, h4 = (ph - 1) / 2 + 1, w4 = (pw - 1) / 2 + 1;
         const int h0 = 8 * ph, w0 = 8 * pw, ih = cfg.image_h, iw = cfg.image_w, Fh = Fe / 2;
-        skws = nullptr;
-        skws_floats = 0;
+        {   // the input-gradient GEMMs run on the caller's stream alone: stream-K region 0 of the forward's workspace, if there is one
+            auto it = c->ws.find("skws");
+            const bool have = it != c->ws.end() && it->second.p && c->skws_zeroed == it->second.p;
+            skws = have ? it->second.p : nullptr;
+            skws_floats = have ? gemm_workspace() : 0;
+        }
         {   // one workspace for every LoRA-gradient call: encoder MLPs (M = F*ntok, D <-> 4D) and, with temporal_lora, ff.net.2
             size_t need = 4;
             if (cfg.lora_type != EDV_LORA_NONE) {

@@ -153,7 +153,6 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g, const G
             __builtin_amdgcn_s_barrier();
         }
         EDV_GEMM_STAMP(3);
-        bool finish = true;  // this workgroup applies the epilogue of the tile
         if (SPLIT && part) {
             // Pieces travel between workgroups on different XCDs (separate L2s).  An agent-scope release / acquire fence pair
             // would do it, but on this part the release writes back the WHOLE L2 (buffer_wbl2) -- measured +140 us per launch
@@ -177,7 +176,6 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g, const G
             __syncthreads();
             const bool last = *s_last != 0;
             __syncthreads();  // s_last is read before the next tile's DMA may overwrite it
-            finish = last;
             if (last) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
@@ -200,9 +198,13 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g, const G
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[0][0][r] += __hip_atomic_load(pa + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                gemm_epilogue_ep<1, 1, STORE, EP>(g, acc, cols, m0, n0, wm * 32, wn * 32, l31, lh);
             }
+        } else {
+            // (a second, separate epilogue call site on purpose: with one shared call behind a flag the split instantiation ran
+            // 142 us instead of 122 us on fc2 at T=8)
+            gemm_epilogue_ep<1, 1, STORE, EP>(g, acc, cols, m0, n0, wm * 32, wn * 32, l31, lh);
         }
-        if (finish) gemm_epilogue_ep<1, 1, STORE, EP>(g, acc, cols, m0, n0, wm * 32, wn * 32, l31, lh);
         EDV_GEMM_STAMP(4);
     }
 }

@@ -250,11 +250,22 @@ int launch_dma(const GemmDesc &d, long long tiles, hipStream_t st) {
     if (d.ws && !plain_forced && left > 0 && tiles > slots / 2 && tiles < 5ll * slots && d.K / DBK >= min_kt) {
         const int nkt = d.K / DBK;
         sp.whole_rounds = (int)(tiles / slots);
-        sp.units = left * nkt;
-        // run length: an even share of the units, but no shorter than 1/4 of a tile's k range (<= ~5 pieces to merge per tile:
-        // the merge is a chain of L2-bypassing loads at the very end of the launch)
-        long long chunk = (sp.units + slots - 1) / slots;
+        long long split_tiles = left;
+        // run length: an even share of the units over ALL workgroups.  When the leftover is too small for that (an even share would
+        // be under 1/4 of a tile's k range, i.e. a handful of workgroups would carry the whole tail and the merge would chain up to
+        // ~5 L2-bypassing loads at the very end of the launch), one whole round joins the split set instead: every workgroup then
+        // runs whole_rounds - 1 whole tiles plus 1 + left/slots tiles' worth of k-tiles, and every split tile has 2-3 pieces.
+        static const bool widen = [] {
+            const char *e = getenv("EDV_GEMM_SPLIT_WIDEN");  // 0: never move a whole round into the split set (A/B runs)
+            return !(e && atoi(e) == 0);
+        }();
         const long long chunk_min = (nkt + 3) / 4;
+        if (widen && sp.whole_rounds > 0 && (left * nkt + slots - 1) / slots < chunk_min && left + slots <= MAX_COUNTERS) {
+            --sp.whole_rounds;
+            split_tiles += slots;
+        }
+        sp.units = split_tiles * nkt;
+        long long chunk = (sp.units + slots - 1) / slots;
         chunk = chunk > chunk_min ? chunk : chunk_min;
         sp.chunk = (int)chunk;
         sp.nsplit = (int)((sp.units + chunk - 1) / chunk);

@@ -247,7 +247,11 @@ int launch_dma(const GemmDesc &d, long long tiles, hipStream_t st) {
     // ... and the tiles are deep: statically assigned persistent workgroups lose 1-10 % against the hardware's dynamic dispatch
     // of the plain grid when a tile is only 12 k-tiles long (K = 384), and win 5-15 % from K = 768 up (warm A/B in
     // profiles/r01_gemm_tile_sweep.txt)
-    if (d.ws && !plain_forced && left > 0 && tiles > slots / 2 && tiles < 5ll * slots && d.K / DBK >= min_kt) {
+    static const int max_rounds = [] {
+        const char *e = getenv("EDV_GEMM_SPLIT_MAX_ROUNDS");  // grids of at least this many rounds run plain (A/B runs)
+        return e && atoi(e) > 0 ? atoi(e) : 8;
+    }();
+    if (d.ws && !plain_forced && left > 0 && tiles > slots / 2 && tiles < (long long)max_rounds * slots && d.K / DBK >= min_kt) {
         const int nkt = d.K / DBK;
         sp.whole_rounds = (int)(tiles / slots);
         long long split_tiles = left;

@@ -251,7 +251,13 @@ int launch_dma(const GemmDesc &d, long long tiles, hipStream_t st) {
         const char *e = getenv("EDV_GEMM_SPLIT_MAX_ROUNDS");  // grids of at least this many rounds run plain (A/B runs)
         return e && atoi(e) > 0 ? atoi(e) : 8;
     }();
-    if (d.ws && !plain_forced && left > 0 && tiles > slots / 2 && tiles < (long long)max_rounds * slots && d.K / DBK >= min_kt) {
+    static const int min_tiles = [] {
+        const char *e = getenv("EDV_GEMM_SPLIT_MIN_TILES");  // smaller grids run plain (A/B runs)
+        return e ? atoi(e) : 16;
+    }();
+    // small grids with deep tiles gain the most: 46 tiles x 48 k-tiles 33.7 -> 16.1 us, the C = 384 motion module's ff.net.2 (276 tiles) 57.5 -> 40.0
+    if (d.ws && !plain_forced && left > 0 && tiles > min_tiles && tiles < (long long)max_rounds * slots &&
+        d.K / DBK >= min_kt) {
         const int nkt = d.K / DBK;
         sp.whole_rounds = (int)(tiles / slots);
         long long split_tiles = left;

@@ -76,6 +76,7 @@ SIGNATURES = {
     "edv_gemm_sb": (C.c_int, [_fp, _fp, _fp, _fp, _i64, _i32, _i32, _fp, _i32, _fp, _fp, C.c_void_p]),
     "edv_conv3x3_sb": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _fp, _fp, C.c_void_p]),
     "edv_conv3x3": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _fp, _fp, C.c_void_p]),
+    "edv_conv3x3_ws": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _fp, _fp, _fp, C.c_size_t, C.c_void_p]),
     "edv_pack_conv3x3": (C.c_int, [_fp, _fp, _i32, _i32, C.c_void_p]),
     "edv_conv_transpose": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
     "edv_attn_spatial_workspace": (C.c_size_t, [_i32, _i32, _i32]),

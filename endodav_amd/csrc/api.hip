@@ -22,8 +22,9 @@ int edv_gemm(const float *A_dev, const float *W_dev, float *C_dev, int64_t M, in
     return gemm(g, (hipStream_t)stream);
 }
 
-int edv_conv3x3(const float *x_dev, const float *wpacked_dev, const float *bias_dev, float *y_dev, int32_t F, int32_t H, int32_t W, int32_t Cin,
-                int32_t Cout, int32_t stride, int32_t pre_relu, int32_t post_relu, const float *R1_dev, const float *R2_dev, void *stream) {
+static int conv3x3_impl(const float *x_dev, const float *wpacked_dev, const float *bias_dev, float *y_dev, int32_t F, int32_t H, int32_t W, int32_t Cin,
+                        int32_t Cout, int32_t stride, int32_t pre_relu, int32_t post_relu, const float *R1_dev, const float *R2_dev, float *ws,
+                        size_t ws_bytes, void *stream) {
     EDV_CHECK(F > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, "empty problem");
     EDV_CHECK(stride == 1 || stride == 2, "stride must be 1 or 2");
     GemmDesc g;
@@ -31,7 +32,20 @@ int edv_conv3x3(const float *x_dev, const float *wpacked_dev, const float *bias_
     g.A = x_dev; g.W = wpacked_dev; g.ldw = 9 * Cin; g.C = y_dev; g.ldc = Cout; g.M = (long long)F * OH * OW; g.N = Cout; g.K = 9 * Cin;
     g.bias = bias_dev; g.act = post_relu ? ACT_RELU : ACT_NONE; g.R1 = R1_dev; g.ldr1 = Cout; g.R2 = R2_dev; g.ldr2 = Cout;
     g.loader = LOAD_CONV3; g.cH = H; g.cW = W; g.cC = Cin; g.cOH = OH; g.cOW = OW; g.cS = stride; g.pre_relu = pre_relu ? 1 : 0;
+    g.ws = ws; g.ws_floats = ws_bytes / sizeof(float);
     return gemm(g, (hipStream_t)stream);
+}
+
+int edv_conv3x3(const float *x_dev, const float *wpacked_dev, const float *bias_dev, float *y_dev, int32_t F, int32_t H, int32_t W, int32_t Cin,
+                int32_t Cout, int32_t stride, int32_t pre_relu, int32_t post_relu, const float *R1_dev, const float *R2_dev, void *stream) {
+    return conv3x3_impl(x_dev, wpacked_dev, bias_dev, y_dev, F, H, W, Cin, Cout, stride, pre_relu, post_relu, R1_dev, R2_dev, nullptr, 0, stream);
+}
+
+int edv_conv3x3_ws(const float *x_dev, const float *wpacked_dev, const float *bias_dev, float *y_dev, int32_t F, int32_t H, int32_t W, int32_t Cin,
+                   int32_t Cout, int32_t stride, int32_t pre_relu, int32_t post_relu, const float *R1_dev, const float *R2_dev, float *workspace_dev,
+                   size_t workspace_bytes, void *stream) {
+    return conv3x3_impl(x_dev, wpacked_dev, bias_dev, y_dev, F, H, W, Cin, Cout, stride, pre_relu, post_relu, R1_dev, R2_dev, workspace_dev,
+                        workspace_bytes, stream);
 }
 
 int edv_gemm_sb(const float *A_dev, const float *W_dev, void *wplanes_dev, float *C_dev, int64_t M, int32_t N, int32_t K, const float *bias_dev,

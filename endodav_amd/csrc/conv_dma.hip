@@ -8,6 +8,8 @@
 // ResidualConvUnits is applied to the A fragments after the LDS read (4 v_max per 4 MFMAs).
 //
 // LDS image, swizzle and pipeline are those of gemm_dma.hip.  Tiles: 64x64 (2x2 waves) or, for Cout <= 32, 128x32 (4x1).
+#include <cstdlib>
+
 #include "gemm_common.hpp"
 
 namespace edv {
@@ -16,8 +18,12 @@ namespace {
 constexpr int CBK = 32;
 __device__ __attribute__((aligned(256))) float g_zero_page[64];
 
-template <int WGM, int EP>
-__global__ __launch_bounds__(256) void conv3_dma_kernel(const GemmDesc g) {
+// SPLIT: the stream-K scheme of gemm_dma.hip for grids that do not fill the part (tiles <= resident workgroups, e.g. layer4_rn: 46
+// tiles of 108 k-tiles on 256 CUs): the tiles' k-tile units are cut into equal contiguous runs, one per workgroup; a run that does
+// not cover a tile's whole k range leaves its accumulators in a workspace slot and the last piece of a tile to arrive merges them in
+// run order and applies the epilogue.  SPLIT = false is the plain grid and compiles to the code it was before.
+template <int WGM, int EP, bool SPLIT>
+__global__ __launch_bounds__(256) void conv3_dma_kernel(const GemmDesc g, const GemmSplit sp) {
     constexpr int WGN = 4 / WGM;
     constexpr int BM = 32 * WGM, BN = 32 * WGN;
     constexpr int IA = BM / 32, IB = BN / 32;  // DMA instructions per wave per k-tile (8 rows x 128 B each)
@@ -27,96 +33,216 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const GemmDesc g) {
     const int wm = wave / WGN, wn = wave % WGN;
     const int tiles_n = (g.N + BN - 1) / BN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
-    const int tm = bid / tiles_n, tn = bid - tm * tiles_n;
-    const long long m0 = (long long)tm * BM;
-    const int n0 = tn * BN;
     const int srow = lane >> 3, spos = lane & 7;
     const float *zero = g_zero_page + spos * 4;
-
-    // per-lane A rows: output pixel -> pointer to the (dy, dx) = (0, 0) tap of its window, validity bits per dy and dx
-    const float *pa[IA];
-    int okmask[IA];  // bits 0..2: row iy0 + dy inside the image; bits 3..5: column ix0 + dx inside
     const int opix = g.cOH * g.cOW;
-#pragma unroll
-    for (int i = 0; i < IA; ++i) {
-        const int r = (BM / 4) * wave + 8 * i + srow;
-        const int c = spos ^ ((r >> 1) & 7);  // logical 16-byte chunk that lives at this LDS position
-        long long m = m0 + r;
-        m = m < g.M ? m : g.M - 1;  // rows past the edge read a valid pixel; their results are never stored
-        const long long f = m / opix;
-        const int p = (int)(m - f * opix);
-        const int oy = p / g.cOW, ox = p - oy * g.cOW;
-        const int iy0 = oy * g.cS - 1, ix0 = ox * g.cS - 1;
-        pa[i] = g.A + ((f * g.cH + iy0) * (long long)g.cW + ix0) * g.cC + c * 4;
-        int mk = 0;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            if (iy0 + d >= 0 && iy0 + d < g.cH) mk |= 1 << d;
-            if (ix0 + d >= 0 && ix0 + d < g.cW) mk |= 8 << d;
-        }
-        okmask[i] = mk;
-    }
-    const float *pb[IB];
-#pragma unroll
-    for (int i = 0; i < IB; ++i) {
-        const int r = (BN / 4) * wave + 8 * i + srow;
-        const int c = spos ^ ((r >> 1) & 7);
-        int n = n0 + r;
-        n = n < g.N ? n : g.N - 1;
-        pb[i] = g.W + (long long)n * g.ldw + c * 4;
-    }
-    auto issue = [&](int kt, int st) {
-        float *sA = smem + st * STAGE, *sB = sA + BM * CBK;
-        const int k = kt * CBK;
-        const int tap = k / g.cC, c0 = k - tap * g.cC;  // uniform: the whole k-tile lies inside one tap
-        const int dy = tap / 3, dx = tap - dy * 3;
-        const long long off = ((long long)dy * g.cW + dx) * g.cC + c0;
-        const int need = (1 << dy) | (8 << dx);
-#pragma unroll
-        for (int i = 0; i < IA; ++i) {
-            const float *src = (okmask[i] & need) == need ? pa[i] + off : zero;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                             (__attribute__((address_space(3))) void *)(sA + ((BM / 4) * wave + 8 * i) * CBK), 16, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < IB; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pb[i] + k),
-                                             (__attribute__((address_space(3))) void *)(sB + ((BN / 4) * wave + 8 * i) * CBK), 16, 0, 0);
-    };
-
-    EpiCols<1> cols;
-    if (EP != 0) cols = gemm_epilogue_prefetch<1>(g, n0, wn * 32, l31);
-    f32x16 acc[1][1];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+    const int nkt = g.K / CBK;
     const int ra = wm * 32 + l31, rb = wn * 32 + l31;
     const int swa = (ra >> 1) & 7, swb = (rb >> 1) & 7;
-    const int nkt = g.K / CBK;
     const bool prelu = g.pre_relu != 0;
 
-    issue(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int st = kt & 1;
-        if (kt + 1 < nkt) issue(kt + 1, st ^ 1);
-        const float *sA = smem + st * STAGE, *sB = sA + BM * CBK;
+    // SPLIT: run `bid` of the split (stride 1: every workgroup of the grid owns one); plain: one whole tile
+    long long u = SPLIT ? (long long)bid * sp.chunk : 0;
+    const long long u_end = SPLIT ? (u + sp.chunk < sp.units ? u + sp.chunk : sp.units) : 0;
+    int seg = 0;
+    bool once = true;
+    for (;;) {
+        int tile, kt0, kt1, lt = 0;
+        float *part = nullptr;
+        if (SPLIT) {
+            if (u >= u_end) break;
+            lt = (int)(u / nkt);
+            kt0 = (int)(u - (long long)lt * nkt);
+            const long long left = u_end - u;
+            kt1 = kt0 + left < nkt ? kt0 + (int)left : nkt;
+            tile = lt;
+            u += kt1 - kt0;
+            if (!(kt0 == 0 && kt1 == nkt)) part = sp.ws + ((long long)bid * 2 + seg) * SPLIT_SLOT;
+            ++seg;
+        } else {
+            if (!once) break;
+            once = false;
+            tile = bid;
+            kt0 = 0;
+            kt1 = nkt;
+        }
+        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        const long long m0 = (long long)tm * BM;
+        const int n0 = tn * BN;
+
+        // per-lane A rows: output pixel -> pointer to the (dy, dx) = (0, 0) tap of its window, validity bits per dy and dx
+        const float *pa[IA];
+        int okmask[IA];  // bits 0..2: row iy0 + dy inside the image; bits 3..5: column ix0 + dx inside
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int cq = 2 * q + lh;
-            f32x4 fa = *reinterpret_cast<const f32x4 *>(&sA[ra * CBK + ((cq ^ swa) << 2)]);
-            const f32x4 fb = *reinterpret_cast<const f32x4 *>(&sB[rb * CBK + ((cq ^ swb) << 2)]);
-            if (prelu) {
-                fa.x = fmaxf(fa.x, 0.f); fa.y = fmaxf(fa.y, 0.f); fa.z = fmaxf(fa.z, 0.f); fa.w = fmaxf(fa.w, 0.f);
+        for (int i = 0; i < IA; ++i) {
+            const int r = (BM / 4) * wave + 8 * i + srow;
+            const int c = spos ^ ((r >> 1) & 7);  // logical 16-byte chunk that lives at this LDS position
+            long long m = m0 + r;
+            m = m < g.M ? m : g.M - 1;  // rows past the edge read a valid pixel; their results are never stored
+            const long long f = m / opix;
+            const int p = (int)(m - f * opix);
+            const int oy = p / g.cOW, ox = p - oy * g.cOW;
+            const int iy0 = oy * g.cS - 1, ix0 = ox * g.cS - 1;
+            pa[i] = g.A + ((f * g.cH + iy0) * (long long)g.cW + ix0) * g.cC + c * 4;
+            int mk = 0;
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+                if (iy0 + d >= 0 && iy0 + d < g.cH) mk |= 1 << d;
+                if (ix0 + d >= 0 && ix0 + d < g.cW) mk |= 8 << d;
+            }
+            okmask[i] = mk;
+        }
+        const float *pb[IB];
+#pragma unroll
+        for (int i = 0; i < IB; ++i) {
+            const int r = (BN / 4) * wave + 8 * i + srow;
+            const int c = spos ^ ((r >> 1) & 7);
+            int n = n0 + r;
+            n = n < g.N ? n : g.N - 1;
+            pb[i] = g.W + (long long)n * g.ldw + c * 4;
+        }
+        auto issue = [&](int kt, int st) {
+            float *sA = smem + st * STAGE, *sB = sA + BM * CBK;
+            const int k = kt * CBK;
+            const int tap = k / g.cC, c0 = k - tap * g.cC;  // uniform: the whole k-tile lies inside one tap
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const long long off = ((long long)dy * g.cW + dx) * g.cC + c0;
+            const int need = (1 << dy) | (8 << dx);
+#pragma unroll
+            for (int i = 0; i < IA; ++i) {
+                const float *src = (okmask[i] & need) == need ? pa[i] + off : zero;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                 (__attribute__((address_space(3))) void *)(sA + ((BM / 4) * wave + 8 * i) * CBK), 16, 0, 0);
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc[0][0], 0, 0, 0);
-        }
+            for (int i = 0; i < IB; ++i)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pb[i] + k),
+                                                 (__attribute__((address_space(3))) void *)(sB + ((BN / 4) * wave + 8 * i) * CBK), 16, 0, 0);
+        };
+
+        EpiCols<1> cols;
+        if (EP != 0) cols = gemm_epilogue_prefetch<1>(g, n0, wn * 32, l31);
+        f32x16 acc[1][1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+
+        issue(kt0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const int st = (kt - kt0) & 1;
+            if (kt + 1 < kt1) issue(kt + 1, st ^ 1);
+            const float *sA = smem + st * STAGE, *sB = sA + BM * CBK;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cq = 2 * q + lh;
+                f32x4 fa = *reinterpret_cast<const f32x4 *>(&sA[ra * CBK + ((cq ^ swa) << 2)]);
+                const f32x4 fb = *reinterpret_cast<const f32x4 *>(&sB[rb * CBK + ((cq ^ swb) << 2)]);
+                if (prelu) {
+                    fa.x = fmaxf(fa.x, 0.f); fa.y = fmaxf(fa.y, 0.f); fa.z = fmaxf(fa.z, 0.f); fa.w = fmaxf(fa.w, 0.f);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc[0][0], 0, 0, 0);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
+        if (SPLIT && part) {
+            // the piece exchange of gemm_dma.hip: agent-scope relaxed atomics (sc1 write-through stores / L2-bypassing loads), an
+            // arrival counter per tile, the last piece to arrive sums all pieces in run order
+#pragma unroll
+            for (int r = 0; r < 16; ++r) __hip_atomic_store(&part[(wave * 16 + r) * 64 + lane], acc[0][0][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long ub = (long long)lt * nkt;
+            const int g0 = (int)(ub / sp.chunk), g1 = (int)((ub + nkt - 1) / sp.chunk);
+            int *s_last = reinterpret_cast<int *>(smem);  // both LDS stages are idle here
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) {
+                const int arrived = __hip_atomic_fetch_add(&sp.cnt[lt], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = arrived == g1 - g0;
+                if (last) __hip_atomic_store(&sp.cnt[lt], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *s_last = last;
+            }
+            __syncthreads();
+            const bool last = *s_last != 0;
+            __syncthreads();
+            if (last) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+                const float *base = sp.ws + (wave * 16) * 64 + lane;
+                int gg = g0;
+                for (; gg + 1 <= g1; gg += 2) {
+                    const float *qa = base + ((long long)gg * 2 + ((long long)gg * sp.chunk >= ub ? 0 : 1)) * SPLIT_SLOT;
+                    const float *qb = base + ((long long)(gg + 1) * 2 + ((long long)(gg + 1) * sp.chunk >= ub ? 0 : 1)) * SPLIT_SLOT;
+                    float ta[16], tb[16];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        ta[r] = __hip_atomic_load(qa + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        tb[r] = __hip_atomic_load(qb + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][0][r] = (acc[0][0][r] + ta[r]) + tb[r];
+                }
+                if (gg <= g1) {
+                    const float *qa = base + ((long long)gg * 2 + ((long long)gg * sp.chunk >= ub ? 0 : 1)) * SPLIT_SLOT;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[0][0][r] += __hip_atomic_load(qa + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                gemm_epilogue_ep<1, 1, STORE_ROWS, EP>(g, acc, cols, m0, n0, wm * 32, wn * 32, l31, lh);
+            }
+        } else {
+            // (its own call site on purpose, see gemm_dma.hip)
+            gemm_epilogue_ep<1, 1, STORE_ROWS, EP>(g, acc, cols, m0, n0, wm * 32, wn * 32, l31, lh);
+        }
     }
-    gemm_epilogue_ep<1, 1, STORE_ROWS, EP>(g, acc, cols, m0, n0, wm * 32, wn * 32, l31, lh);
+}
+
+template <int WGM, int EP>
+int conv_slots() {
+    static const int slots = [] {
+        int dev = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3_dma_kernel<WGM, EP, true>, 256, 0) != hipSuccess) return 0;
+        if (per_cu > 4) per_cu = 4;  // 32 KB of LDS: the API says 5, the part places 4 (scratch/ubench/lds_residency.hip)
+        return cus * per_cu;
+    }();
+    return slots;
+}
+
+template <int WGM, int EP>
+int launch_conv_ep(const GemmDesc &d, long long tiles, hipStream_t st) {
+    static const bool split_on = [] {
+        const char *e = getenv("EDV_CONV_SPLIT");  // 0: plain grid always (A/B runs)
+        return !(e && atoi(e) == 0);
+    }();
+    const int nkt = d.K / CBK;
+    GemmSplit sp{0, 1, 0, 1, 0, nullptr, nullptr};
+    const int slots = conv_slots<WGM, EP>();
+    // grids that do not fill the part and whose tiles are deep (Cin >= 192: 54+ k-tiles), or that leave most of it idle (8 tiles per
+    // resident slot).  Measured (scratch/kb_conv_split.py, plain / split us): layer4_rn 46 tiles x 108 k-tiles 91 / 31, resize_layers.3
+    // 276 x 108: 144 / 89, layer3_rn 172 x 54: 48 / 38, RCU at 19x19 46 x 18: 18.9 / 14.2 -- but RCU at 37x37 172 x 18: 19.3 / 24.9 and at
+    // 74x74 685 x 18: 39.8 / 46.4, so shallow tiles on a half-full grid stay plain.
+    if (split_on && d.ws && slots > 0 && tiles > 16 && tiles <= slots && tiles <= SPLIT_MAX_COUNTERS && nkt >= 18 &&
+        (nkt >= 48 || tiles * 8 <= slots)) {
+        sp.units = tiles * nkt;
+        long long chunk = (sp.units + slots - 1) / slots;
+        const long long chunk_min = (nkt + 3) / 4;
+        chunk = chunk > chunk_min ? chunk : chunk_min;
+        sp.chunk = (int)chunk;
+        sp.nsplit = (int)((sp.units + chunk - 1) / chunk);
+        sp.cnt = reinterpret_cast<int *>(d.ws);
+        sp.ws = d.ws + SPLIT_MAX_COUNTERS;
+        if ((size_t)SPLIT_MAX_COUNTERS + (size_t)sp.nsplit * 2 * SPLIT_SLOT <= d.ws_floats && (uintptr_t)d.ws % 16 == 0) {
+            hipLaunchKernelGGL((conv3_dma_kernel<WGM, EP, true>), dim3((unsigned)sp.nsplit), dim3(256), 0, st, d, sp);
+            EDV_LAUNCH_OK();
+            return 0;
+        }
+    }
+    hipLaunchKernelGGL((conv3_dma_kernel<WGM, EP, false>), dim3((unsigned)tiles), dim3(256), 0, st, d, sp);
+    EDV_LAUNCH_OK();
+    return 0;
 }
 
 template <int WGM>
@@ -124,14 +250,11 @@ int launch_conv(const GemmDesc &d, hipStream_t st) {
     constexpr int BM = 32 * WGM, BN = 32 * (4 / WGM);
     const long long tiles = ((d.M + BM - 1) / BM) * (long long)((d.N + BN - 1) / BN);
     EDV_CHECK(tiles > 0 && tiles < (1ll << 31), "bad grid");
-    const dim3 grid((unsigned)tiles), block(256);
     switch (epilogue_kind(d)) {
-        case 1: hipLaunchKernelGGL((conv3_dma_kernel<WGM, 1>), grid, block, 0, st, d); break;
-        case 3: hipLaunchKernelGGL((conv3_dma_kernel<WGM, 3>), grid, block, 0, st, d); break;
-        default: hipLaunchKernelGGL((conv3_dma_kernel<WGM, 0>), grid, block, 0, st, d); break;
+        case 1: return launch_conv_ep<WGM, 1>(d, tiles, st);
+        case 3: return launch_conv_ep<WGM, 3>(d, tiles, st);
+        default: return launch_conv_ep<WGM, 0>(d, tiles, st);
     }
-    EDV_LAUNCH_OK();
-    return 0;
 }
 
 }  // namespace

@@ -14,6 +14,17 @@ __device__ __forceinline__ float apply_act(float v, int act) {
     return v;
 }
 
+// Stream-K work split of one launch of the LDS-DMA kernels (gemm_dma.hip explains the scheme; conv_dma.hip uses it for small grids).
+struct GemmSplit {
+    int whole_rounds, chunk, nsplit, stride;
+    long long units;
+    float *ws;   // piece slots (after the counters)
+    int *cnt;    // one arrival counter per split tile
+};
+constexpr int SPLIT_SLOT = 64 * 64;        // floats per piece: a 64x64 or 128x32 tile in accumulator order, (wave * 16 + r) * 64 + lane
+constexpr int SPLIT_MAX_COUNTERS = 4096;   // >= the tiles a launch may split
+
+
 // XCD-aware, bijective block remap: blocks b and b+8 share an XCD (and its L2); give each XCD a contiguous run of
 // logical tiles so that tiles sharing an operand panel hit the same L2.
 __device__ __forceinline__ int xcd_remap(int bid, int nblk) {

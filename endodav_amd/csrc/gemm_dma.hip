@@ -42,14 +42,9 @@ constexpr int DSTAGE = (DBM + DBN) * DBK;  // floats per stage (16 KB)
 //
 // Why it matters (profiles/r01_gemm_tile_sweep.txt, warm clocks): a CU retires tiles at a fixed MFMA-bound rate, so a grid of
 // 1032 tiles on 256 CUs (N = 384 at 8 x 1370 rows) takes as long as 1280 tiles: fc2 138 us vs 112 us at 1020 tiles.
-struct GemmSplit {
-    int whole_rounds, chunk, nsplit, stride;
-    long long units;
-    float *ws;   // slots (after the counters)
-    int *cnt;    // one arrival counter per leftover tile
-};
-constexpr int SLOT = DBM * DBN;   // floats per workspace slot; element (wave, r, lane) at (wave * 16 + r) * 64 + lane
-constexpr int MAX_COUNTERS = 4096;  // >= resident slots of any CDNA4 part (leftover tiles < slots)
+// (GemmSplit, SLOT and MAX_COUNTERS live in gemm_common.hpp: conv_dma.hip uses the same scheme)
+constexpr int SLOT = SPLIT_SLOT;
+constexpr int MAX_COUNTERS = SPLIT_MAX_COUNTERS;
 
 // SPLIT = false is the plain grid (one whole tile per workgroup): the split bookkeeping and the merge compile away, which
 // keeps the hot instantiation at 48 VGPRs and its code in the instruction cache (with the merge inlined the same launches ran

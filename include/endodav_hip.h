@@ -160,6 +160,11 @@ int edv_conv3x3_sb(const float *x_dev, const float *wpacked_dev, void *wplanes_d
 int edv_conv3x3(const float *x_dev, const float *wpacked_dev, const float *bias_dev, float *y_dev, int32_t F, int32_t H, int32_t W,
                 int32_t Cin, int32_t Cout, int32_t stride, int32_t pre_relu, int32_t post_relu, const float *R1_dev,
                 const float *R2_dev, void *stream);
+/* The same with a stream-K workspace (edv_gemm_workspace() bytes, zero-filled once, as for edv_gemm): grids that do not fill the part
+ * (e.g. 384 -> 64 channels at 19x19: 46 tiles of 108 k-tiles) are split along K over the resident workgroups and merged in-kernel. */
+int edv_conv3x3_ws(const float *x_dev, const float *wpacked_dev, const float *bias_dev, float *y_dev, int32_t F, int32_t H, int32_t W,
+                   int32_t Cin, int32_t Cout, int32_t stride, int32_t pre_relu, int32_t post_relu, const float *R1_dev,
+                   const float *R2_dev, float *workspace_dev, size_t workspace_bytes, void *stream);
 /* Repack a torch Conv2d weight [Cout,Cin,3,3] to [Cout][3][3][Cin]. */
 int edv_pack_conv3x3(const float *w_dev, float *wpacked_dev, int32_t Cout, int32_t Cin, void *stream);
 

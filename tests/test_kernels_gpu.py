@@ -206,8 +206,14 @@ def test_gemm_rejects_bad_k(lib, cuda):
     (1, 70, 98, 32, 32, 1, False, True, 0),      # output_conv2.0 + ReLU
     (2, 5, 7, 16, 32, 1, False, True, 0),        # micro head
     (2, 1, 2, 64, 64, 2, False, False, 1),       # degenerate grid
+    (8, 19, 19, 384, 64, 1, False, False, 0),    # layer4_rn: 46 tiles of 108 k-tiles -> split along K with a workspace
+    (8, 37, 37, 192, 64, 1, False, False, 0),    # layer3_rn: 172 tiles of 54 k-tiles
+    (8, 37, 37, 384, 384, 2, False, False, 0),   # resize_layers[3] at T=8: 276 tiles of 108 k-tiles
+    (8, 37, 37, 64, 64, 1, True, False, 2),      # ResidualConvUnit at 37x37: 172 tiles of 18 k-tiles, both residual adds in the merged epilogue
+    (4, 74, 74, 64, 64, 1, True, True, 1),       # 343 tiles
 ])
-def test_conv3x3(lib, cuda, Fr, H, W, Cin, Cout, stride, pre, post, res):
+@pytest.mark.parametrize("split", [False, True], ids=["plain", "streamk"])
+def test_conv3x3(lib, cuda, Fr, H, W, Cin, Cout, stride, pre, post, res, split):
     x = rnd(Fr, Cin, H, W, seed=1)
     w = rnd(Cout, Cin, 3, 3, seed=2, scale=1 / math.sqrt(9 * Cin))
     b = rnd(Cout, seed=3, scale=0.1)
@@ -226,6 +232,16 @@ def test_conv3x3(lib, cuda, Fr, H, W, Cin, Cout, stride, pre, post, res):
     wp = torch.empty(Cout * 9 * Cin, device=cuda)
     _lib.check(lib.edv_pack_conv3x3(wd.data_ptr(), wp.data_ptr(), Cout, Cin, st()))
     y = torch.full((Fr, OH, OW, Cout), float("nan"), device=cuda)
+    if split:
+        ws, nbytes = gemm_ws(lib, cuda)
+        for _ in range(2):  # twice: the second launch depends on the first leaving the arrival counters at zero
+            y.fill_(float("nan"))
+            _lib.check(lib.edv_conv3x3_ws(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), y.data_ptr(), Fr, H, W, Cin, Cout, stride, int(pre), int(post),
+                                          _lib.ptr(r1), _lib.ptr(r2), ws.data_ptr(), nbytes, st()), "edv_conv3x3_ws")
+            torch.cuda.synchronize()
+            assert int(ws[:COUNTER_FLOATS].view(torch.int32).abs().sum()) == 0
+            close(y.permute(0, 3, 1, 2), ref, 3e-6, "conv3x3 stream-K")
+        return
     _lib.check(lib.edv_conv3x3(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), y.data_ptr(), Fr, H, W, Cin, Cout, stride, int(pre), int(post),
                                _lib.ptr(r1), _lib.ptr(r2), st()), "edv_conv3x3")
     close(y.permute(0, 3, 1, 2), ref, 3e-6, "conv3x3")

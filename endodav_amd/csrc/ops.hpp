@@ -95,7 +95,7 @@ int groupnorm(const float *x, const float *w, const float *b, float *y, float *s
 // ------------------------------------------------------------------------------------------
 // resampling / elementwise (resample.hip)
 // ------------------------------------------------------------------------------------------
-int patchify(const float *x, float *cols, int F, int H, int W, int ih, int iw, hipStream_t st);
+int patchify(const float *x, float *cols, int F, int H, int W, int ih, int iw, hipStream_t st, int ld = 588)  /* ld: row stride of cols, >= 588; the tail of a row is zero-filled */;
 int bilinear(const float *x, float *y, int F, int H, int W, int C, int OH, int OW, int act, hipStream_t st, const float *add = nullptr);  // y = up(x) (+ add)
 int dot_channels(const float *x, const float *w, const float *b, float *y, long long M, int C, int act, hipStream_t st);
 int cls_rows(const float *cls, const float *pos, float *tokens, int F, int ntok, int D, hipStream_t st);

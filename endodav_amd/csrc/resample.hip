@@ -34,13 +34,17 @@ __device__ __forceinline__ void lin_coord(int dst, int in, int out, float ratio,
 inline float lin_ratio(int in, int out) { return out > 1 ? (float)(in - 1) / (float)(out - 1) : 0.f; }
 
 __global__ __launch_bounds__(256) void patchify_kernel(const float *__restrict__ x, float *__restrict__ cols, int F, int H, int W, int ih, int iw,
-                                                        float rh, float rw) {
+                                                        float rh, float rw, int ld) {
     const int ph = ih / 14, pw = iw / 14;
-    const long long total = (long long)F * ph * pw * 588;
+    const long long total = (long long)F * ph * pw * ld;
     const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
-        const int k = (int)(i % 588);
-        long long r = i / 588;
+        const int k = (int)(i % ld);
+        long long r = i / ld;
+        if (k >= 588) {  // row padding (the engine pads K to a multiple of 32 for the LDS-DMA GEMM)
+            cols[i] = 0.f;
+            continue;
+        }
         const int px = (int)(r % pw);
         r /= pw;
         const int py = (int)(r % ph);
@@ -199,12 +203,12 @@ inline int grid_for(long long total, int cap = 8192) {
 
 }  // namespace
 
-int patchify(const float *x, float *cols, int F, int H, int W, int ih, int iw, hipStream_t st) {
+int patchify(const float *x, float *cols, int F, int H, int W, int ih, int iw, hipStream_t st, int ld) {
     EDV_CHECK(x && cols, "null operand");
-    EDV_CHECK(F > 0 && H > 0 && W > 0, "empty problem");
+    EDV_CHECK(F > 0 && H > 0 && W > 0 && ld >= 588, "empty problem");
     EDV_CHECK(ih % 14 == 0 && iw % 14 == 0 && ih > 0 && iw > 0, "image_shape must be a multiple of 14");
-    const long long total = (long long)F * (ih / 14) * (iw / 14) * 588;
-    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, st, x, cols, F, H, W, ih, iw, lin_ratio(H, ih), lin_ratio(W, iw));
+    const long long total = (long long)F * (ih / 14) * (iw / 14) * ld;
+    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, st, x, cols, F, H, W, ih, iw, lin_ratio(H, ih), lin_ratio(W, iw), ld);
     EDV_LAUNCH_OK();
     return 0;
 }

@@ -2,7 +2,8 @@
 //
 // Same contract and epilogues as gemm.hip.  What changes is how the 64x64x32 tiles reach LDS: each wave issues
 // four DMA instructions per k-tile (8 rows x 128 B each) that write LDS directly — no VGPR round trip, no ds_write,
-// 48 instead of 100 registers per lane and 32 KB of LDS for two stages, so 5 workgroups fit a CU instead of 4.
+// 48 instead of 100 registers per lane and 32 KB of LDS for two stages (which places 4 workgroups per CU: the LDS allocation
+// granule is 1280 B, so five 32 KB blocks do not fit 160 KB -- scratch/ubench/lds_residency.hip).
 // The ablation in scratch/ubench/gemm_ablate.hip priced exactly these staging instructions at ~20 % of the loop.
 //
 // LDS image: unpadded 128-byte rows (the DMA destination is lane-linear), 16-byte chunk c of row r stored at chunk
@@ -30,8 +31,8 @@ namespace {
 constexpr int DBK = 32, DBM = 64, DBN = 64;
 constexpr int DSTAGE = (DBM + DBN) * DBK;  // floats per stage (16 KB)
 
-// Work split of one launch (host-made, passed by value).  G = gridDim.x persistent workgroups, all co-resident (4 per CU: what
-// 32 KB of LDS really places, scratch/ubench/lds_residency.hip).  Every workgroup first computes `whole_rounds` whole output tiles
+// Work split of one launch (host-made, passed by value).  G = gridDim.x persistent workgroups, all co-resident (3 per CU: the split
+// instantiation holds ~116 VGPRs, and a grid beyond the real residency loses everything the split gains).  Every workgroup first computes `whole_rounds` whole output tiles
 // (tile = round * G + id).  The remaining tiles % G tiles are `units` = leftover_tiles * k_tiles k-tile units; they are cut into
 // `nsplit` contiguous runs of `chunk` units, run j going to the workgroup with id j * stride (spread over the CUs).  A run that
 // does not cover a tile's whole k range leaves its raw accumulators in workspace slot (j * 2 + segment), bumps the tile's
@@ -41,7 +42,8 @@ constexpr int DSTAGE = (DBM + DBN) * DBK;  // floats per stage (16 KB)
 // G = tiles, one whole tile each.
 //
 // Why it matters (profiles/r01_gemm_tile_sweep.txt, warm clocks): a CU retires tiles at a fixed MFMA-bound rate, so a grid of
-// 1032 tiles on 256 CUs (N = 384 at 8 x 1370 rows) takes as long as 1280 tiles: fc2 138 us vs 112 us at 1020 tiles.
+// 1032 tiles on 256 CUs (N = 384 at 8 x 1370 rows) takes as long as 1280 tiles: fc2 138 us vs 112 us at 1020 tiles; with the split
+// 121 us.  It pays for deep tiles (K >= 768) and for small grids; 12-k-tile tiles lose more to the static assignment than they gain.
 // (GemmSplit, SLOT and MAX_COUNTERS live in gemm_common.hpp: conv_dma.hip uses the same scheme)
 constexpr int SLOT = SPLIT_SLOT;
 constexpr int MAX_COUNTERS = SPLIT_MAX_COUNTERS;

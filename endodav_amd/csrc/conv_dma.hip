@@ -44,7 +44,6 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const GemmDesc g, const 
     // SPLIT: run `bid` of the split (stride 1: every workgroup of the grid owns one); plain: one whole tile
     long long u = SPLIT ? (long long)bid * sp.chunk : 0;
     const long long u_end = SPLIT ? (u + sp.chunk < sp.units ? u + sp.chunk : sp.units) : 0;
-    int seg = 0;
     bool once = true;
     for (;;) {
         int tile, kt0, kt1, lt = 0;
@@ -56,9 +55,9 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const GemmDesc g, const 
             const long long left = u_end - u;
             kt1 = kt0 + left < nkt ? kt0 + (int)left : nkt;
             tile = lt;
+            // slot 0 = the piece that holds the run's first unit, slot 1 = the other one (the rule of gemm_dma.hip)
+            if (!(kt0 == 0 && kt1 == nkt)) part = sp.ws + ((long long)bid * 2 + (u == (long long)bid * sp.chunk ? 0 : 1)) * SPLIT_SLOT;
             u += kt1 - kt0;
-            if (!(kt0 == 0 && kt1 == nkt)) part = sp.ws + ((long long)bid * 2 + seg) * SPLIT_SLOT;
-            ++seg;
         } else {
             if (!once) break;
             once = false;

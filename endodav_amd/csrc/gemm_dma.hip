@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g, const G
     const int run = (SPLIT && sp.units > 0 && bid % sp.stride == 0 && bid / sp.stride < sp.nsplit) ? bid / sp.stride : -1;
     long long u = run >= 0 ? (long long)run * sp.chunk : 0;
     const long long u_end = run >= 0 ? (u + sp.chunk < sp.units ? u + sp.chunk : sp.units) : 0;
-    int round = 0, seg = 0;
+    int round = 0;
     for (;;) {
         int tile, kt0, kt1, lt = 0;
         float *part = nullptr;
@@ -86,9 +86,11 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g, const G
             kt1 = kt0 + left < nkt ? kt0 + (int)left : nkt;
             tile = tile_l0 + t;
             lt = t;
+            // A run longer than a tile's k range has up to three segments: the tail of a tile, whole tiles, the head of a tile.  Only
+            // the first and the last can be pieces.  Slot 0 = the piece that holds the run's first unit, slot 1 = the other one -- the
+            // rule the merge applies from the tile's side (run start inside the tile -> slot 0).
+            if (!(kt0 == 0 && kt1 == nkt)) part = sp.ws + ((long long)run * 2 + (u == (long long)run * sp.chunk ? 0 : 1)) * SLOT;
             u += kt1 - kt0;
-            if (!(kt0 == 0 && kt1 == nkt)) part = sp.ws + ((long long)run * 2 + seg) * SLOT;
-            ++seg;  // slot 0 = the piece holding this run's first unit, slot 1 = the head of the next tile
         } else {
             break;
         }

@@ -85,3 +85,82 @@ def test_conv_split_equals_plain(lib, cuda, ws, Fr, H, W, Cin, Cout, stride):
     assert torch.equal(outs[1], outs[2])
     scale = outs[0].abs().max().item()
     assert (outs[0] - outs[1]).abs().max().item() <= 3e-6 * scale
+
+
+# ---- spatial attention, forward and backward: the task / run / piece geometry depends on (frames, tokens, heads) --------------------
+def shapes_attn(n=24, seed=11):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        heads = int(rng.choice([1, 2, 3, 6, 12, 16]))
+        N = int(rng.choice([33, 64, 65, 127, 200, 257, 321, 400, 577, 700]))
+        want_tasks = int(rng.choice([3, 40, 130, 260, 500, 520, 530, 800, 1100]))
+        Fr = max(1, min(48, want_tasks // (heads * ((N + 127) // 128))))
+        out.append((Fr, N, heads))
+    return sorted(set(out))
+
+
+@pytest.mark.parametrize("Fr,N,heads", shapes_attn())
+def test_attention_forward_backward_sweep(lib, cuda, Fr, N, heads):
+    D = heads * 64
+    g = torch.Generator().manual_seed(Fr * 1000 + N * 10 + heads)
+    qkv = torch.randn(Fr * N, 3 * D, generator=g) * 1.5
+    gout = torch.randn(Fr * N, D, generator=g)
+    x = qkv.double().requires_grad_(True)
+    t = x.reshape(Fr, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    ref = ((t[0] * 0.125) @ t[1].transpose(-2, -1)).softmax(-1) @ t[2]
+    ref = ref.transpose(1, 2).reshape(Fr * N, D)
+    (dref,) = torch.autograd.grad(ref, x, gout.double())
+    qd, gd = qkv.to(cuda), gout.to(cuda)
+    o = torch.full((Fr * N, D), float("nan"), device=cuda)
+    lse = torch.full((Fr * heads * N,), float("nan"), device=cuda)
+    nb = lib.edv_attn_spatial_workspace(Fr, N, heads)
+    wsf = torch.full((max(nb // 4, 4),), float("nan"), device=cuda)
+    _lib.check(lib.edv_attn_spatial(qd.data_ptr(), o.data_ptr(), Fr, N, heads, wsf.data_ptr(), nb, lse.data_ptr(), st()), "edv_attn_spatial")
+    ref_d = ref.detach()
+    assert (o.cpu().double() - ref_d).abs().max().item() <= 5e-6 * ref_d.abs().max().item()
+    delta = torch.empty(Fr * heads * N, device=cuda)
+    dqkv = torch.full((Fr * N, 3 * D), float("nan"), device=cuda)
+    nbb = lib.edv_attn_spatial_bwd_workspace(Fr, N, heads)
+    wsb = torch.full((max(nbb // 4, 4),), float("nan"), device=cuda)
+    _lib.check(lib.edv_attn_spatial_bwd(qd.data_ptr(), o.data_ptr(), gd.data_ptr(), lse.data_ptr(), delta.data_ptr(), dqkv.data_ptr(), Fr, N, heads,
+                                        wsb.data_ptr(), nbb, st()), "edv_attn_spatial_bwd")
+    got = dqkv.cpu().double()
+    for j in range(3):
+        a, b = got[:, j * D:(j + 1) * D], dref[:, j * D:(j + 1) * D]
+        assert (a - b).abs().max().item() <= 1.5e-5 * b.abs().max().item(), "qkv"[j]
+
+
+# ---- temporal attention (pixel-per-workgroup kernels with head groups): clip length x pixels x width ----------------------------------
+def shapes_temporal(n=20, seed=13):
+    rng = np.random.default_rng(seed)
+    out = []
+    for _ in range(n):
+        T = int(rng.choice([1, 2, 3, 5, 8, 9, 12, 16, 17, 24, 32]))
+        Cc = int(rng.choice([32, 64, 128, 192, 256, 384, 768, 1024]))
+        P = int(rng.choice([1, 7, 50, 361, 500]))
+        Bc = int(rng.choice([1, 2]))
+        if Bc * T * P * Cc <= 12_000_000:
+            out.append((Bc, T, P, Cc))
+    return sorted(set(out))
+
+
+@pytest.mark.parametrize("Bc,T,P,Cc", shapes_temporal())
+def test_temporal_attention_forward_backward_sweep(lib, cuda, Bc, T, P, Cc):
+    heads, d = 8, Cc // 8
+    g = torch.Generator().manual_seed(T * 100 + P + Cc)
+    qkv = torch.randn(Bc * T * P, 3 * Cc, generator=g) * 1.2
+    gout = torch.randn(Bc * T * P, Cc, generator=g)
+    x = qkv.double().requires_grad_(True)
+    t = x.reshape(Bc, T, P, 3, heads, d).permute(3, 0, 2, 4, 1, 5)  # [3, B, P, h, T, d]
+    a = ((t[0] @ t[1].transpose(-1, -2)) * d ** -0.5).softmax(-1)
+    ref = (a @ t[2]).permute(0, 3, 1, 2, 4).reshape(Bc * T * P, Cc)
+    (dref,) = torch.autograd.grad(ref, x, gout.double())
+    qd, gd = qkv.to(cuda), gout.to(cuda)
+    o = torch.full((Bc * T * P, Cc), float("nan"), device=cuda)
+    _lib.check(lib.edv_attn_temporal(qd.data_ptr(), o.data_ptr(), Bc, T, P, Cc, heads, st()), "edv_attn_temporal")
+    ref_d = ref.detach()
+    assert (o.cpu().double() - ref_d).abs().max().item() <= 4e-6 * max(ref_d.abs().max().item(), 1e-30)
+    dqkv = torch.full((Bc * T * P, 3 * Cc), float("nan"), device=cuda)
+    _lib.check(lib.edv_attn_temporal_bwd(qd.data_ptr(), gd.data_ptr(), dqkv.data_ptr(), Bc, T, P, Cc, heads, st()), "edv_attn_temporal_bwd")
+    assert (dqkv.cpu().double() - dref).abs().max().item() <= 1e-5 * dref.abs().max().item()

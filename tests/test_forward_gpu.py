@@ -134,6 +134,38 @@ def test_baseline_config_vits_518_t8_against_oracle(cuda):
         assert e <= DISP_RTOL and de <= DEPTH_RTOL and ar <= ABS_REL_MAX
 
 
+@pytest.mark.parametrize("encoder,head,image_shape,clip,input_hw,opts", [
+    ("vits", (64, [48, 96, 192, 384]), (154, 210), (2, 3), (154, 210), dict(lora_type="dvlora", disable_conv_head=True)),
+    ("vits", (64, [48, 96, 192, 384]), (266, 350), (1, 5), (300, 400), dict(lora_type="ssb", temporal_lora=True)),
+    ("vits", (32, [32, 32, 64, 64]), (98, 126), (3, 7), (98, 126), dict(lora_type="lora", disable_conv_head=True, include_cls_token=False, pe="rope")),
+    ("vitb", (128, [96, 192, 384, 768]), (126, 182), (1, 9), (126, 182), dict(lora_type="dvlora", disable_conv_head=True, out_sigmoid=True)),
+    ("vits", (64, [48, 96, 192, 384]), (392, 294), (1, 17), (392, 294), dict(lora_type="none", inv_sigmoid=True, use_bn=True)),
+], ids=["154x210_B2T3", "266x350_T5_resized_ssb_tlora_convhead", "98x126_B3T7_nocls_rope", "vitb_126x182_T9_outsigmoid", "392x294_T17_bn_convhead"])
+def test_odd_geometries_against_oracle(cuda, encoder, head, image_shape, clip, input_hw, opts):
+    """Geometries no fixture covers (non-square grids, odd clip lengths, several clips, resized input, option mixes): every tile edge,
+    frame-group split and split-K plan differs from the golden cases.  HIP vs the CPU oracle on the same weights and clip."""
+    import endodav_amd
+    from endodav_amd import synth
+
+    kwargs = dict(encoder=encoder, features=head[0], out_channels=head[1], image_shape=image_shape, **opts)
+    model = endodav_amd.endodav(**kwargs).eval()
+    synth.fill_module_(model)
+    B, T = clip
+    x = torch.from_numpy(synth.synth_clip(B, T, input_hw[0], input_hw[1], seed=5, kind="tissue"))
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        ref = orc.forward(sd, x, H.oracle_config(kwargs))
+    model = model.to(cuda)
+    with torch.no_grad():
+        out = model(x.to(cuda))
+    for s in range(4):
+        a, b = out[("disp", s)].cpu().numpy(), ref[("disp", s)].numpy()
+        assert a.shape == b.shape
+        e, ar = H.rel_err(a, b), H.abs_rel(a, b)
+        de, _ = H.depth_gate(a, b)
+        assert e <= DISP_RTOL and de <= DEPTH_RTOL and ar <= ABS_REL_MAX, (s, e, de, ar)
+
+
 def test_clips_are_independent_at_full_size(cuda):
     """Size-independent property at BASELINE's full size (no oracle run needed): forward never mixes clips, so a
     batch of two 518x518 T=8 clips equals the two clips run alone -- up to summation order only, because the split of the

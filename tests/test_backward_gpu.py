@@ -262,6 +262,26 @@ def test_reference_default_trainable_set_gradients(lib, cuda):
     print(f"\n[reference default trainable set, 224x280 T=2] {len(names)} tensors, worst scale-relative gradient error vs the fp64 graph {worst:.2e}")
 
 
+def test_gradients_on_an_odd_geometry(lib, cuda):
+    """Two clips of three frames on a non-square 9 x 13 patch grid, conv head, ssb + temporal_lora, everything the reference would train
+    in that configuration: a geometry and an option mix no other gradient test has; fp64 oracle graph."""
+    kwargs = dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384], image_shape=(126, 182), lora_type="ssb", temporal_lora=True)
+    model = endodav_amd.endodav(**kwargs, pretrained_path=None)
+    synth.fill_module_(model)
+    names = []
+    for n, p in model.named_parameters():
+        p.requires_grad = ((".mlp.fc" in n or ".ff.net.2." in n) and n.rsplit(".", 1)[-1] in ("lora_A", "lora_B")) or n.startswith("head.conv_depth_")
+        if p.requires_grad:
+            names.append(n)
+    x = torch.from_numpy(synth.synth_clip(2, 3, 150, 200, seed=6, kind="tissue"))
+    model = model.to(cuda).train()
+    gouts = upstream([(6, 1, h, w) for (h, w) in model.output_shapes()])
+    ref64, _ = oracle_grads(model, kwargs, x, names, gouts, torch.float64)
+    hip, _ = hip_grads(model, x, names, gouts, cuda)
+    worst = check(hip, ref64, tol=5e-4)
+    print(f"\n[126x182 B=2 T=3 conv head ssb + temporal_lora] {len(names)} tensors, worst scale-relative gradient error vs the fp64 graph {worst:.2e}")
+
+
 def test_training_forward_equals_inference(lib, cuda):
     """Same kernels, same values; the inference path only orders the head differently (the fusion blocks' skip branches
     run on a second stream and are added where x is produced), which moves the result by fp32 rounding."""

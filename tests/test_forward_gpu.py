@@ -166,6 +166,36 @@ def test_odd_geometries_against_oracle(cuda, encoder, head, image_shape, clip, i
         assert e <= DISP_RTOL and de <= DEPTH_RTOL and ar <= ABS_REL_MAX, (s, e, de, ar)
 
 
+def test_run_to_run_reproducibility_at_full_size(cuda):
+    """Every reduction in the engine has a fixed order (stream-K pieces merged in run order, two-stage sums, no floating-point atomics), so
+    the same clip gives the same bits on every call -- with two encoder frame groups, the head's side stream and the split kernels active."""
+    import endodav_amd
+    from endodav_amd import synth
+
+    model = endodav_amd.endodav(encoder="vits", features=64, out_channels=[48, 96, 192, 384], image_shape=(518, 518), lora_type="dvlora",
+                                disable_conv_head=True).eval()
+    synth.fill_module_(model)
+    model = model.to(cuda)
+    x = torch.from_numpy(synth.synth_clip(1, 8, 518, 518, seed=1, kind="tissue")).to(cuda)
+    with torch.no_grad():
+        ref = [o.clone() for o in model(x).values()]
+        for _ in range(12):
+            out = model(x)
+            assert all(torch.equal(a, b) for a, b in zip(out.values(), ref))
+    endodav_amd.mark_only_part_as_trainable(model, warm_up=True)
+    model.train()
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def grads():
+        model.zero_grad(set_to_none=True)
+        sum(o.mean() for o in model(x).values()).backward()
+        return [p.grad.clone() for p in params]
+
+    g0 = grads()
+    for _ in range(3):
+        assert all(torch.equal(a, b) for a, b in zip(grads(), g0))
+
+
 def test_clips_are_independent_at_full_size(cuda):
     """Size-independent property at BASELINE's full size (no oracle run needed): forward never mixes clips, so a
     batch of two 518x518 T=8 clips equals the two clips run alone -- up to summation order only, because the split of the

@@ -105,7 +105,12 @@ __device__ __forceinline__ void gemm_epilogue_elem(const GemmDesc &g, float accv
 // share.  A workgroup timeline (scratch/ubench/gemm_trace.hip) showed 7.8 us of a 27 us workgroup life inside it.  Every
 // encoder linear and every convolution needs only: identity row maps, no P1, a compile-time activation.
 //   EP = 0: general;  EP = 1 + ACT (ACT_NONE / ACT_GELU / ACT_RELU): fast.
+//   EP = 5: row-mapped output (and residual) with one period >= 32 rows, no activation -- the patch-embed GEMM, whose rows go to
+//           frame f's token slots behind the class token and take the position table as a per-frame-periodic residual.
 inline int epilogue_kind(const GemmDesc &d) {
+    if (d.store == STORE_ROWS && !d.P1 && !d.R2 && d.act == ACT_NONE && d.c_map.period >= 32 && d.c_map.inner == 1 &&
+        (!d.R1 || (d.r1_map.period == d.c_map.period && d.r1_map.inner == 1)))
+        return 5;
     if (d.store != STORE_ROWS || d.P1 || d.c_map.period != 0 || (d.R1 && d.r1_map.period != 0)) return 0;
     if (d.act != ACT_NONE && d.act != ACT_GELU && d.act != ACT_RELU) return 0;
     return 1 + d.act;
@@ -177,11 +182,45 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmDesc &g, f32x16 (&a
     }
 }
 
+// EP = 5 (see epilogue_kind): rows m = mb + dr of a 32-row block cross at most one period boundary, so one division per block suffices
+template <int FM, int FN>
+__device__ __forceinline__ void gemm_epilogue_mapped(const GemmDesc &g, f32x16 (&acc)[FM][FN], const EpiCols<FN> &cols, long long m0, int n0, int wrow,
+                                                     int wcol, int l31, int lh) {
+    const int P = g.c_map.period;
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = n0 + wcol + j * 32 + l31;
+        if (n >= g.N) continue;
+        const float bias = cols.bias[j], gam = cols.gam[j];
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const long long mb = m0 + wrow + i * 32 + 4 * lh;
+            const int left = (int)(g.M - mb < 32 ? g.M - mb : 32);
+            const long long f0 = mb / P;
+            const int in0 = (int)(mb - f0 * P);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int dr = (r & 3) + 8 * (r >> 2);
+                if (dr >= left) continue;
+                const int t = in0 + dr;
+                const int wrap = t >= P ? 1 : 0;
+                const long long f = f0 + wrap;
+                const int pin = t - wrap * P;
+                float v = (acc[i][j][r] + bias) * gam;
+                if (g.R1) v += g.R1[(f * g.r1_map.stride + g.r1_map.offset + pin) * g.ldr1 + n];
+                g.C[(f * g.c_map.stride + g.c_map.offset + pin) * g.ldc + n] = v;
+            }
+        }
+    }
+}
+
 template <int FM, int FN, int STORE, int EP>
 __device__ __forceinline__ void gemm_epilogue_ep(const GemmDesc &g, f32x16 (&acc)[FM][FN], const EpiCols<FN> &cols, long long m0, int n0, int wrow,
                                                  int wcol, int l31, int lh) {
     if constexpr (EP == 0)
         gemm_epilogue<FM, FN, STORE>(g, acc, m0, n0, wrow, wcol, l31, lh);
+    else if constexpr (EP == 5)
+        gemm_epilogue_mapped<FM, FN>(g, acc, cols, m0, n0, wrow, wcol, l31, lh);
     else
         gemm_epilogue_fast<FM, FN, EP - 1>(g, acc, cols, m0, n0, wrow, wcol, l31, lh);
 }

@@ -323,6 +323,7 @@ int gemm_dma(const GemmDesc &d, hipStream_t st) {
         case 1: return launch_dma<STORE_ROWS, 1>(d, tiles, st);
         case 2: return launch_dma<STORE_ROWS, 2>(d, tiles, st);
         case 3: return launch_dma<STORE_ROWS, 3>(d, tiles, st);
+        case 5: return launch_dma<STORE_ROWS, 5>(d, tiles, st);
         default: return launch_dma<STORE_ROWS, 0>(d, tiles, st);
     }
 }

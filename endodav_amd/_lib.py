@@ -107,7 +107,8 @@ SIGNATURES = {
     "edv_dilate2": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, C.c_void_p]),
     "edv_pixel_unshuffle": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
     "edv_attn_temporal": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
-    "edv_groupnorm": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _f32, C.c_void_p]),
+    "edv_groupnorm_workspace": (C.c_size_t, [_i32, _i32, _i32]),
+    "edv_groupnorm": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _f32, _fp, C.c_size_t, C.c_void_p]),
     "edv_geglu": (C.c_int, [_fp, _fp, _i64, _i32, C.c_void_p]),
     "edv_rope_qk": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
     "edv_bilinear": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),

@@ -171,9 +171,11 @@ int edv_rope_qk(float *qkv_dev, const float *table_dev, int32_t B, int32_t T, in
     return rope_qk(qkv_dev, table_dev, B, T, P, C, transpose != 0, (hipStream_t)stream);
 }
 
+size_t edv_groupnorm_workspace(int32_t F, int32_t P, int32_t C) { return groupnorm_workspace(F, P, C) * sizeof(float); }
+
 int edv_groupnorm(const float *x_dev, const float *w_dev, const float *b_dev, float *y_dev, float *stats_dev, int32_t F, int32_t P, int32_t C,
-                  int32_t groups, float eps, void *stream) {
-    return groupnorm(x_dev, w_dev, b_dev, y_dev, stats_dev, F, P, C, groups, eps, (hipStream_t)stream);
+                  int32_t groups, float eps, float *workspace_dev, size_t workspace_bytes, void *stream) {
+    return groupnorm(x_dev, w_dev, b_dev, y_dev, stats_dev, F, P, C, groups, eps, (hipStream_t)stream, workspace_dev, workspace_bytes / sizeof(float));
 }
 
 int edv_geglu(const float *x_dev, float *y_dev, int64_t M, int32_t inner, void *stream) { return geglu(x_dev, y_dev, M, inner, (hipStream_t)stream); }

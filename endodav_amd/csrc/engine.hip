@@ -477,7 +477,15 @@ struct Run {
         const float *w, *b;
         EDV_TRY(param(p + ".norm.weight", &w));
         EDV_TRY(param(p + ".norm.bias", &b));
-        EDV_TRY(groupnorm(xin, w, b, gn, stats, F, P, C, 32, 1e-6f, st));
+        // coalesced two-stage statistics for the large maps only: [8,1369,192] 23.3 -> 16.3 us, [8,5476,64] 34.5 -> 18.3 us, but the small ones
+        // ([8,361,384] 11.1 -> 14.7 us) lose to the third launch
+        float *gnpart = nullptr;
+        size_t gnpart_n = 0;
+        if ((long long)F * P * C >= 1500000ll) {
+            gnpart_n = groupnorm_workspace(F, P, C);
+            EDV_TRY(wsbuf(sc_ + "gnpart", gnpart_n, &gnpart));
+        }
+        EDV_TRY(groupnorm(xin, w, b, gn, stats, F, P, C, 32, 1e-6f, st, gnpart, gnpart_n));
         c->launches += 2;
         EDV_TRY(param(p + ".proj_in.weight", &w));
         EDV_TRY(param(p + ".proj_in.bias", &b));

@@ -89,8 +89,9 @@ int rope_qk(float *qkv, const float *table, int B, int T, int P, int C, bool tra
 // y[out_map(m)] (+)= act(LN(x[in_map(m)]) * w + b (+ pe[(m / rows_per_frame) % T]));  act: ACT_NONE / ACT_GELU
 int layernorm(const float *x, RowMap in_map, const float *w, const float *b, float *y, RowMap out_map, long long rows, int dim,
               float eps, const float *pe, int rows_per_frame, int T, hipStream_t st, int act = ACT_NONE, bool accumulate = false);
-int groupnorm(const float *x, const float *w, const float *b, float *y, float *stats, int F, int P, int C, int groups, float eps,
-              hipStream_t st);
+size_t groupnorm_workspace(int F, int P, int C);  // floats, for the coalesced two-stage statistics
+int groupnorm(const float *x, const float *w, const float *b, float *y, float *stats, int F, int P, int C, int groups, float eps, hipStream_t st,
+              float *part = nullptr, size_t part_floats = 0);  // part = null: one workgroup per (frame, group) reads its strided slab
 
 // ------------------------------------------------------------------------------------------
 // resampling / elementwise (resample.hip)

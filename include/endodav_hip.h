@@ -192,9 +192,12 @@ int edv_attn_temporal(const float *qkv_dev, float *out_dev, int32_t B, int32_t T
  * transpose != 0 applies the adjoint (the gradient of the rotation with respect to its input). */
 int edv_rope_qk(float *qkv_dev, const float *table_dev, int32_t B, int32_t T, int32_t P, int32_t C, int32_t transpose, void *stream);
 
-/* GroupNorm(32 groups) on channels-last x [F,P,C] (motion_module.py:84,110). */
+/* GroupNorm(32 groups) on channels-last x [F,P,C] (motion_module.py:84,110).  With a workspace (edv_groupnorm_workspace bytes) the
+ * statistics are taken in two coalesced stages (per 32-pixel chunk and channel, then merged per group with the parallel-variance
+ * formula); with workspace_dev = NULL one workgroup per (frame, group) reads its strided slab twice.  Same values to fp32 rounding. */
+size_t edv_groupnorm_workspace(int32_t F, int32_t P, int32_t C);
 int edv_groupnorm(const float *x_dev, const float *w_dev, const float *b_dev, float *y_dev, float *stats_dev /* [F*32*2] scratch */,
-                  int32_t F, int32_t P, int32_t C, int32_t groups, float eps, void *stream);
+                  int32_t F, int32_t P, int32_t C, int32_t groups, float eps, float *workspace_dev, size_t workspace_bytes, void *stream);
 
 /* GEGLU, attention.py:363-384: y[m, j] = x[m, j] * gelu(x[m, inner + j]), x [M, 2*inner]. */
 int edv_geglu(const float *x_dev, float *y_dev, int64_t M, int32_t inner, void *stream);

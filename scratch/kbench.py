@@ -170,7 +170,10 @@ if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "gn":
     for (F_, P, Cc) in ((8, 1369, 192), (8, 361, 384), (8, 1369, 64), (8, 5476, 64)):
         x = torch.randn(F_, P, Cc, device=dev); w = torch.randn(Cc, device=dev); b = torch.randn(Cc, device=dev)
         y = torch.empty_like(x); stats = torch.empty(F_ * 64, device=dev)
-        t = timeit(lambda: _lib.check(lib.edv_groupnorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), F_, P, Cc, 32, 1e-6, st())))
+        t = timeit(lambda: _lib.check(lib.edv_groupnorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), F_, P, Cc, 32, 1e-6, None, 0, st())))
+        nb = lib.edv_groupnorm_workspace(F_, P, Cc); gws = torch.empty(nb // 4, device=dev)
+        t2 = timeit(lambda: _lib.check(lib.edv_groupnorm(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), stats.data_ptr(), F_, P, Cc, 32, 1e-6, gws.data_ptr(), nb, st())))
+        print(f"   two-stage statistics: {t2*1e6:8.1f} us")
         print(f"groupnorm F={F_} P={P} C={Cc}: {t*1e6:7.1f} us (stats + apply)  {x.numel()*4*2/t/1e12:5.2f} TB/s", flush=True)
 
 

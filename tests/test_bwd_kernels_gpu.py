@@ -265,7 +265,7 @@ def test_groupnorm_bwd(lib, cuda, Fr, P, Cc, acc):
     (ref,) = grad_of(lambda xx: F.group_norm(xx.permute(0, 2, 1), 32, w.double(), b.double(), 1e-6).permute(0, 2, 1), [x], g)
     xd, wd, bd = x.to(cuda), w.to(cuda), b.to(cuda)
     y, stats, sums = torch.empty_like(xd), torch.empty(Fr * 32 * 2, device=cuda), torch.empty(Fr * 32 * 2, device=cuda)
-    _lib.check(lib.edv_groupnorm(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), stats.data_ptr(), Fr, P, Cc, 32, 1e-6, st()))
+    _lib.check(lib.edv_groupnorm(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), stats.data_ptr(), Fr, P, Cc, 32, 1e-6, None, 0, st()))
     base = rnd(Fr, P, Cc, seed=5)
     dx = base.to(cuda) if acc else torch.full((Fr, P, Cc), float("nan"), device=cuda)
     _lib.check(lib.edv_groupnorm_bwd(xd.data_ptr(), stats.data_ptr(), wd.data_ptr(), keep(g.to(cuda)), sums.data_ptr(), dx.data_ptr(), Fr, P, Cc, 32,

@@ -392,14 +392,18 @@ def test_attn_temporal_rejects_long_clips(lib, cuda):
 
 
 # ----------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("Fr,P,Cc", [(3, 25, 64), (2, 1369, 192), (2, 361, 384), (4, 6, 32), (1, 5476, 64)])
-def test_groupnorm(lib, cuda, Fr, P, Cc):
+@pytest.mark.parametrize("Fr,P,Cc", [(3, 25, 64), (2, 1369, 192), (2, 361, 384), (4, 6, 32), (1, 5476, 64), (2, 33, 1024), (3, 100, 96), (8, 5476, 64)])
+@pytest.mark.parametrize("two_stage", [False, True], ids=["strided", "two_stage"])
+def test_groupnorm(lib, cuda, Fr, P, Cc, two_stage):
     x = rnd(Fr, P, Cc, seed=1, scale=2) + 3.0  # mean >> std: one-pass E[x^2]-E[x]^2 would lose digits
     w, b = rnd(Cc, seed=2) + 1, rnd(Cc, seed=3, scale=0.1)
     ref = F.group_norm(x.double().permute(0, 2, 1), 32, w.double(), b.double(), 1e-6).permute(0, 2, 1)
     xd, wd, bd = x.to(cuda), w.to(cuda), b.to(cuda)
-    y, stats = torch.empty_like(xd), torch.empty(Fr * 32 * 2, device=cuda)
-    _lib.check(lib.edv_groupnorm(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), stats.data_ptr(), Fr, P, Cc, 32, 1e-6, st()))
+    y, stats = torch.full_like(xd, float("nan")), torch.empty(Fr * 32 * 2, device=cuda)
+    nb = lib.edv_groupnorm_workspace(Fr, P, Cc) if two_stage else 0
+    ws = torch.full((max(nb // 4, 4),), float("nan"), device=cuda)
+    _lib.check(lib.edv_groupnorm(xd.data_ptr(), wd.data_ptr(), bd.data_ptr(), y.data_ptr(), stats.data_ptr(), Fr, P, Cc, 32, 1e-6,
+                                 ws.data_ptr() if two_stage else None, nb, st()))
     close(y, ref, 5e-6, "groupnorm")
 
 

@@ -1916,7 +1916,7 @@ int edv_forward(edv_ctx *ctx, const float *x_dev, int32_t B, int32_t T, int32_t 
     EDV_CHECK((long long)B * T <= 65535, "too many frames in one call");
     for (int k = 0; k < 4; ++k) EDV_CHECK(disp_dev[k], "null output");
     if (ctx->train) {
-        const edv_config &c = ctx->cfg;
+        EDV_CHECK(!(ctx->cfg.use_bn), "the fine-tune step with use_bn=True is not built (train-mode BatchNorm uses batch statistics)");
         EDV_CHECK(!ctx->capture, "stage capture and training are exclusive");
     }
     Run r(ctx, (hipStream_t)stream);

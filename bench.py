@@ -1,24 +1,31 @@
 #!/usr/bin/env python3
 """bench.py — frames/s of EndoDAV's per-clip forward on MI355X (BASELINE.json metric).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--T 8] [--encoder vits]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--T 8] [--encoder vits] [--train]
 
 One "step" = one pass of the hot path (edv_forward) over one synthetic 518x518 clip of T frames that is
 already resident in HBM.  N > 1: one process per GPU (torch.distributed.run), every rank runs its own
 clip per step, no data-path collective (clips are independent: SURVEY.md §8e) — weak scaling; the only
-NCCL(RCCL) traffic is the barrier and the MAX-reduction of the elapsed time around the timed region.
+NCCL(RCCL) traffic is the barrier and the MAX-reduction of the elapsed time around the timed region
+(``endodav_amd.parallel.timed_region``, the same code the gloo world-2 test runs).
 
 Rank 0 prints ONE JSON line: value = total frames of all ranks / max-over-ranks time, plus
-  roofline      the dominant kernel (spatial attention, fp32 MFMA) priced as algorithmic FLOPs per launch over
-                its mean launch time, measured with HIP event pairs on the launch stream inside the timed region
-  cpu_baseline  the oracle (PyTorch-CPU restatement, kind "port") timed on this box's host cores on a bounded
-                sample of the same workload (rank 0, N = 1 only).
+  roofline            the dominant kernel class by time -- the dense fp32-MFMA GEMM (every F.linear / 1x1 conv) -- priced as
+                      algorithmic FLOP over launch time, measured with HIP event pairs on the launch stream inside the timed region
+  roofline_attention  the second one: the encoder's fused spatial attention, same method
+  roofline_hbm        the bandwidth-bound kernels (LayerNorm, GroupNorm, bilinear resamples, GEGLU, the final 1x1 convolution,
+                      patchify): algorithmic bytes over launch time against the 8 TB/s HBM3E peak
+  cpu_baseline        the oracle (PyTorch-CPU restatement, kind "port") timed on this box's host cores on a bounded
+                      sample of the same workload (rank 0, N = 1 only): median of 5 clips at n = the box's cores and at n = 8.
+--train times the fine-tune step (BASELINE.json config 4 with --encoder vitb --T 16 --image 224x280): forward + the photometric
+loss (endodav_amd/losses.py, PyTorch) + HIP backward + ONE in-place all-reduce of the flat gradient buffer + AdamW.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -32,8 +39,10 @@ MODELS = {"vits": VITS, "vitb": VITB, "vitl": VITL}
 DIMS = {"vits": (384, 12, 6), "vitb": (768, 12, 12), "vitl": (1024, 24, 16)}
 # matmul+conv FLOPs per 518x518 frame, FlopCounterMode over the reference
 GFLOP_PER_FRAME = {"vits": 121.1, "vitb": 403.9, "vitl": 1403.8}
-LIN_STEPS = 2  # timed steps whose dense-GEMM launches are bracketed with HIP events (see main)
+LIN_STEPS = 2  # timed steps whose kernels are bracketed with HIP events (see main)
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0         # same guide, "HBM3E peak BW" (spec; 6.29 TB/s measured with a float4 copy)
+PROFILE_ROUND = "r02"         # profiles/<round>_{gemm,attn,hbm}_traffic.json hold the PMC traffic of this round's kernels
 
 
 def parse():
@@ -43,36 +52,42 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--T", type=int, default=8, help="frames per clip (BASELINE headline: 8)")
     ap.add_argument("--encoder", default="vits", choices=sorted(MODELS))
-    ap.add_argument("--image", type=int, default=518)
+    ap.add_argument("--image", default="518", help="image_shape: S (square) or HxW, e.g. 224x280 (the trainer's); frames come in at that size "
+                    "(--train with 224x280: at the trainer's 256x320)")
     ap.add_argument("--clips", type=int, default=1, help="clips per GPU per step (a batch [B,T,...] through one forward)")
     ap.add_argument("--conv-head", action="store_true", help="the four HeadDepth heads instead of the VDA head (reference default; with --train "
                     "their convolutions are trainable next to the LoRA factors, endodav/layers.py:5-34)")
     ap.add_argument("--lora", default="dvlora", choices=["none", "lora", "dvlora", "ssb"], help="lora_type (the reference's train_video*.sh use ssb)")
     ap.add_argument("--temporal-lora", action="store_true", help="LoRA on ff.net.2 of the motion modules too (--temporal_lora)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket the dominant kernel with HIP events")
+    ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(16, cores): the box's CPU share)")
-    ap.add_argument("--train", action="store_true", help="time the fine-tune step instead (forward + loss + HIP backward + gradient "
+    ap.add_argument("--train", action="store_true", help="time the fine-tune step instead (forward + photometric loss + HIP backward + gradient "
                     "all-reduce + AdamW on the LoRA factors; BASELINE.json config 4 shape with --encoder vitb --T 16); not the headline metric")
-    return ap.parse_args()
+    ap.add_argument("--l1-loss", action="store_true", help="--train with the round-1 L1 stand-in instead of the photometric loss (A/B of the loss's share)")
+    args = ap.parse_args()
+    hw = [int(v) for v in str(args.image).lower().split("x")]
+    args.image_hw = (hw[0], hw[0]) if len(hw) == 1 else (hw[0], hw[1])
+    return args
 
 
-def measured_traffic(encoder, T, image, clips=1, which="gemm"):
+def measured_traffic(encoder, T, image_hw, clips=1, which="gemm"):
     """HBM-side bytes per launch of a kernel from the committed rocprofv3 --pmc passes (collected in their own runs,
     FETCH_SIZE doubled as the gfx950 guide prescribes); None when no pass matches this workload."""
-    path = os.path.join(ROOT, "profiles", f"r01_{which}_traffic.json")
-    try:
-        with open(path) as f:
-            rec = json.load(f)
-    except OSError:
-        return None
-    if rec.get("config") == {"encoder": encoder, "T": T, "image": image} and clips == 1:
-        return rec["traffic_bytes_per_launch"]
-    return None
+    for rnd in (PROFILE_ROUND, "r01"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_{which}_traffic.json")
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+        except OSError:
+            continue
+        if rec.get("config") == {"encoder": encoder, "T": T, "image": image_hw[0]} and image_hw[0] == image_hw[1] and clips == 1:
+            return rec, os.path.relpath(path, ROOT)
+    return None, None
 
 
-def cpu_baseline(kwargs, T, image, threads):
-    """Oracle on the host cores: 1 warm-up clip + timed clips until ~20 s or 3 clips."""
+def cpu_baseline(kwargs, T, image_hw, threads):
+    """Oracle on the host cores: 1 warm-up clip + 5 timed clips, median, at n = the box's cores and at n = 8."""
     import torch
 
     import endodav_amd
@@ -80,21 +95,59 @@ def cpu_baseline(kwargs, T, image, threads):
     from oracle import endodav_oracle as orc
 
     cores = threads or min(16, os.cpu_count() or 1)
-    torch.set_num_threads(cores)
-    model = endodav_amd.endodav(**kwargs, image_shape=(image, image), lora_type="dvlora", disable_conv_head=True).eval()
+    model = endodav_amd.endodav(**kwargs, image_shape=image_hw, lora_type="dvlora", disable_conv_head=True).eval()
     synth.fill_module_(model)
     sd = {k: v.detach() for k, v in model.state_dict().items()}
-    cfg = orc.OracleConfig(encoder=kwargs["encoder"], image_shape=(image, image), lora_type="dvlora", disable_conv_head=True)
-    x = torch.from_numpy(synth.synth_clip(1, T, image, image, seed=0))
-    with torch.no_grad():
-        orc.forward(sd, x, cfg)  # warm-up
-        n, t0 = 0, time.perf_counter()
-        while n < 3 and (n == 0 or time.perf_counter() - t0 < 20.0):
-            orc.forward(sd, x, cfg)
-            n += 1
-        dt = time.perf_counter() - t0
-    return {"value": round(n * T / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"{n} clip(s) of T={T} at {image}x{image} after 1 warm-up clip, oracle/endodav_oracle.py (torch {torch.__version__} CPU fp32)"}
+    cfg = orc.OracleConfig(encoder=kwargs["encoder"], image_shape=image_hw, lora_type="dvlora", disable_conv_head=True)
+    x = torch.from_numpy(synth.synth_clip(1, T, image_hw[0], image_hw[1], seed=0))
+
+    def run(n_threads, n_clips=5):
+        torch.set_num_threads(n_threads)
+        times = []
+        with torch.no_grad():
+            orc.forward(sd, x, cfg)  # warm-up
+            for _ in range(n_clips):
+                t0 = time.perf_counter()
+                orc.forward(sd, x, cfg)
+                times.append(time.perf_counter() - t0)
+        return statistics.median(times), times
+
+    med, times = run(cores)
+    out = {"value": round(T / med, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+           "sample": f"median of {len(times)} clips of T={T} at {image_hw[0]}x{image_hw[1]} after 1 warm-up clip, oracle/endodav_oracle.py "
+                     f"(torch {torch.__version__} CPU fp32)", "s_per_clip": round(med, 3)}
+    if cores != 8 and (os.cpu_count() or 1) >= 8:
+        med8, t8 = run(8)
+        out["at_8_threads"] = {"value": round(T / med8, 3), "cores": 8, "s_per_clip": round(med8, 3), "clips": len(t8)}
+    return out
+
+
+def hbm_roofline(model, encoder, T, image_hw, clips):
+    """Bandwidth-bound kernel classes bracketed in the last LIN_STEPS steps: algorithmic bytes / launch time against the HBM peak."""
+    from endodav_amd import _lib
+
+    rec, src = measured_traffic(encoder, T, image_hw, clips, "hbm")
+    rows = {}
+    tot_b = tot_ms = 0.0
+    for cls in _lib.HBM_CLASSES:
+        n, ms = model.profile_read(cls)
+        _, by = model.profile_work(cls)
+        if n == 0 or ms <= 0:
+            continue
+        gbs = by / (ms * 1e-3) / 1e9
+        rows[cls] = {"launches": n, "avg_launch_us": round(ms / n * 1e3, 2), "algorithmic_bytes_per_launch": round(by / n, 1),
+                     "achieved": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4),
+                     "traffic": None if rec is None else rec.get("traffic_bytes_per_launch", {}).get(cls)}
+        tot_b += by
+        tot_ms += ms
+    if not rows:
+        return None
+    gbs = tot_b / (tot_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(gbs / PEAK_HBM_GBS, 4),
+            "ms_per_step": round(tot_ms / LIN_STEPS, 4), "kernels": rows,
+            "traffic_unit": None if rec is None else f"bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, {src})",
+            "note": "algorithmic bytes = every tensor a kernel reads or writes, once; launch time by HIP events (kernel + the in-order gap before it); "
+                    "groupnorm = statistics + apply launches of one call"}
 
 
 def main():
@@ -104,6 +157,7 @@ def main():
 
     import endodav_amd
     from endodav_amd import parallel, synth
+    from endodav_amd.pipeline import ClipPipeline
 
     rank, world, local = parallel.env_rank_world()
     if world != args.gpus:
@@ -118,51 +172,45 @@ def main():
     parallel.init("nccl", dev)
 
     kwargs = MODELS[args.encoder]
-    T, S = args.T, args.image
-    model = endodav_amd.endodav(**kwargs, image_shape=(S, S), lora_type=args.lora, temporal_lora=args.temporal_lora,
+    T, (SH, SW) = args.T, args.image_hw
+    model = endodav_amd.endodav(**kwargs, image_shape=(SH, SW), lora_type=args.lora, temporal_lora=args.temporal_lora,
                                 disable_conv_head=not args.conv_head).eval()
     synth.fill_module_(model)
     model = model.to(dev)
     Bc = args.clips
-    x = torch.from_numpy(synth.synth_clip(Bc, T, S, S, seed=rank)).to(dev)  # resident in HBM before timing
-
-    def sync_all():
-        torch.cuda.synchronize(dev)
-        parallel.barrier()
+    in_hw = (256, 320) if (args.train and (SH, SW) == (224, 280)) else (SH, SW)  # the trainer feeds 256x320 frames (options.py:128-135)
+    x = torch.from_numpy(synth.synth_clip(Bc, T, in_hw[0], in_hw[1], seed=rank)).to(dev)  # resident in HBM before timing
 
     if args.train:
-        return train_bench(args, model, x, dev, rank, world, kwargs, sync_all)
+        return train_bench(args, model, x, dev, rank, world, kwargs)
+    events = not args.no_kernel_events
     with torch.no_grad():
-        for _ in range(max(args.warmup, 1)):
-            out = model(x)
-        sync_all()
-        if not args.no_kernel_events:
+        model(x)  # creates the context (profile_* need one)
+        if events:
             model.profile_enable([])
-        sync_all()
-        # Kernel timing happens inside the timed region, in its last LIN_STEPS steps: there every dense-GEMM launch and every
-        # attention call is bracketed with a HIP event pair on its launch stream, and the encoder runs single-stream so that a
-        # bracket times the kernel alone (by default the engine overlaps two frame groups on internal streams for short
-        # clips, which is what the other steps run).  Event pairs around ~100 launches cost ~5 % of those steps.
+        # Kernel timing happens inside the timed region, in its last LIN_STEPS steps: there every dense-GEMM launch, every attention call
+        # and every bandwidth-bound kernel is bracketed with a HIP event pair on its launch stream, and the encoder runs single-stream so
+        # that a bracket times the kernel alone (by default the engine overlaps two frame groups on internal streams for short
+        # clips, which is what the other steps run).  Those steps run ~10 % slower than the others (no overlap, ~300 event pairs).
         lin_from = args.steps - min(LIN_STEPS, args.steps)
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            if i == lin_from and not args.no_kernel_events:
-                model.set_encoder_streams(1)
-                model.profile_set(["attn_spatial", "linear"])
-            out = model(x)
-        torch.cuda.synchronize(dev)
-        parallel.barrier()
-        dt = time.perf_counter() - t0
-        if not args.no_kernel_events:
-            model.set_encoder_streams(-1)
-    dt = parallel.max_over_ranks(dt, dev)
+        out = {}
 
-    # Dominant kernel by time (profiles/r01_i_bench_T8_kernel_stats.csv): gemm_dma_kernel, the dense F.linear / 1x1-conv GEMM
-    # (49 % of the step over its two epilogue variants); second: the encoder attention call (20 %).  Both are bracketed
-    # with HIP event pairs on their launch stream inside the timed region; the engine accounts the algorithmic work of the
-    # bracketed linear launches itself (2 M N K and A, W, C (+ residual) once).
-    roofline = roofline_attn = None
-    if not args.no_kernel_events:
+        def step(i):
+            if i == lin_from and events:
+                model.set_encoder_streams(1)
+                model.profile_set(["attn_spatial", "linear"] + list(endodav_amd._lib.HBM_CLASSES))
+            out["maps"] = model(x)
+
+        dt, _ = parallel.timed_region(step, args.steps, max(args.warmup, 1), dev)
+        if events:
+            model.set_encoder_streams(-1)
+    out = out["maps"]
+
+    # Dominant kernel by time (profiles/r02_*_kernel_stats.csv): gemm_dma_kernel, the dense F.linear / 1x1-conv GEMM; second: the encoder
+    # attention call.  Both are bracketed with HIP event pairs on their launch stream inside the timed region; the engine accounts the
+    # algorithmic work of the bracketed linear launches itself (2 M N K and A, W, C (+ residual) once).
+    roofline = roofline_attn = roofline_hbm = None
+    if events:
         n_h, ms_h = model.profile_read("linear")          # patch embed + DPT head
         fl_h, by_h = model.profile_work("linear")
         n_e, ms_e = model.profile_read("linear_encoder")  # qkv / proj / fc1 / fc2 of the encoder blocks
@@ -170,10 +218,12 @@ def main():
         n_l, ms_l, fl_l, by_l = n_h + n_e, ms_h + ms_e, fl_h + fl_e, by_h + by_e
         if n_l > 0 and ms_l > 0:
             achieved = fl_l / (ms_l * 1e-3) / 1e12
-            roofline = {"kernel": "gemm_dma_kernel (every F.linear / 1x1 conv of the step: qkv, proj, fc1, fc2 of the 12 blocks + the head's)",
+            rec, src = measured_traffic(args.encoder, T, (SH, SW), Bc, "gemm")
+            roofline = {"kernel": "gemm_dma_kernel (every F.linear / 1x1 conv of the step: qkv, proj, fc1, fc2 of the encoder blocks + the head's)",
                         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(args.encoder, T, S, Bc, "gemm"),
-                        "traffic_unit": "bytes per launch, mean over the step's launches (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_gemm_traffic.json)",
+                        "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None if rec is None else rec["traffic_bytes_per_launch"],
+                        "traffic_unit": None if rec is None else f"bytes per launch, mean over the step's launches (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, {src}; "
+                                        "collected in separate --pmc passes of this command, not re-measured in this run)",
                         "algorithmic_bytes_per_launch": round(by_l / n_l, 1), "launches": n_l, "avg_launch_ms": round(ms_l / n_l, 4),
                         "flop_per_launch": round(fl_l / n_l, 1), "peak_dtype": "f32 MFMA (v_mfma_f32_32x32x2_f32), dense"}
             if n_e > 0 and ms_e > 0:  # the same kernel on the encoder's four shapes only (the head's small GEMMs are HBM- / launch-bound)
@@ -183,55 +233,56 @@ def main():
                                                 "share_of_linear_flop": round(fl_e / fl_l, 4)}
         n, ms = model.profile_read("attn_spatial")
         D, depth, heads = DIMS[args.encoder]
-        ntok = (S // 14) ** 2 + 1
+        ntok = (SH // 14) * (SW // 14) + 1
         flops = 4.0 * ntok * ntok * 64 * heads * T * Bc  # QK^T + PV, 2 FLOP per MAC, per launch (one encoder block, all frames)
         if n > 0 and ms > 0:
             achieved = flops / (ms / n * 1e-3) / 1e12
-            roofline_attn = {"kernel": "attn_spatial_kernel + attn_combine_kernel (one encoder-block attention call)", "bound": "mfma",
+            rec, src = measured_traffic(args.encoder, T, (SH, SW), Bc, "attn")
+            roofline_attn = {"kernel": "attn_spatial_kernel (one encoder-block attention call)", "bound": "mfma",
                              "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": measured_traffic(args.encoder, T, S, Bc, "attn"),
-                             "traffic_unit": "bytes per call (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_attn_traffic.json)",
+                             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None if rec is None else rec["traffic_bytes_per_launch"],
+                             "traffic_unit": None if rec is None else f"bytes per call (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, {src})",
                              "algorithmic_bytes_per_launch": 4.0 * ntok * T * Bc * heads * 64 * 4,
                              "launches": n, "avg_launch_ms": round(ms / n, 4), "flop_per_launch": flops,
                              "peak_dtype": "f32 MFMA (v_mfma_f32_32x32x2_f32), dense"}
-    # PCIe-inclusive variant (never `value`): pinned host clip -> HBM, forward, the four maps -> pinned host
+        roofline_hbm = hbm_roofline(model, args.encoder, T, (SH, SW), Bc)
+    # PCIe-inclusive variant (never `value`): pinned host clip -> HBM on a copy stream while the previous clip computes, forward, the four
+    # maps -> pinned host memory on a second copy stream (endodav_amd/pipeline.py); the reference does both transfers synchronously
     pcie_value = None
     if world == 1:
         model.profile_enable([])
+        pipe = ClipPipeline(model, dev)
         xh = x.cpu().pin_memory()
-        oh = [torch.empty_like(v, device="cpu").pin_memory() for v in out.values()]
-        with torch.no_grad():
-            torch.cuda.synchronize(dev)
-            n_p = max(args.steps // 2, 1)
-            t1 = time.perf_counter()
-            for _ in range(n_p):
-                xd = xh.to(dev, non_blocking=True)
-                o = model(xd)
-                for h, v in zip(oh, o.values()):
-                    h.copy_(v, non_blocking=True)
-            torch.cuda.synchronize(dev)
-            pcie_value = Bc * T * n_p / (time.perf_counter() - t1)
+        n_p = max(args.steps, 4)
+        for _ in pipe.run(xh for _ in range(3)):  # allocate the staging buffers
+            pass
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        taken = sum(1 for _ in pipe.run(xh for _ in range(n_p)))
+        torch.cuda.synchronize(dev)
+        pcie_value = Bc * T * taken / (time.perf_counter() - t1)
     finite = bool(torch.isfinite(out[("disp", 0)]).all().item())
     if rank == 0:
         frames = world * Bc * T * args.steps
         value = frames / dt
+        px = (SH * SW) / (518.0 * 518.0)
         line = {
-            "metric": "depth frames/sec (518x518, T=8 clip)" if (S, T) == (518, 8) else f"depth frames/sec ({S}x{S}, T={T} clip)",
+            "metric": "depth frames/sec (518x518, T=8 clip)" if (SH, SW, T) == (518, 518, 8) else f"depth frames/sec ({SH}x{SW}, T={T} clip)",
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"ViT-{args.encoder[-1].upper()} endodav (features {kwargs['features']}, out_channels {kwargs['out_channels']}, "
-                                   f"{args.lora} r=4, {'conv head' if args.conv_head else 'VDA head'}), {Bc} synthetic {S}x{S} T={T} clip(s) per GPU per step (BASELINE.json configs[1] shape), "
-                                   "hash-initialised weights", "encoder": args.encoder, "T": T, "image": [S, S], "clips_per_gpu_per_step": Bc,
-                       "parallelism": f"clip-sharded x{world}, no data-path collective"},
-            "model_tflop_per_clip": round(GFLOP_PER_FRAME[args.encoder] * T / 1e3 * (S / 518.0) ** 2, 4),
-            "model_tflops": round(GFLOP_PER_FRAME[args.encoder] * (S / 518.0) ** 2 * value / 1e3, 2),
+                                   f"{args.lora} r=4, {'conv head' if args.conv_head else 'VDA head'}), {Bc} synthetic {SH}x{SW} T={T} clip(s) per GPU per step "
+                                   "(BASELINE.json configs[1] shape at the defaults), hash-initialised weights", "encoder": args.encoder, "T": T,
+                       "image": [SH, SW], "clips_per_gpu_per_step": Bc, "parallelism": f"clip-sharded x{world}, no data-path collective"},
+            "model_tflop_per_clip": round(GFLOP_PER_FRAME[args.encoder] * T / 1e3 * px, 4),
+            "model_tflops": round(GFLOP_PER_FRAME[args.encoder] * px * value / 1e3, 2),
             "launches_per_step": model.launch_count(), "device_mem_mb": round(model.device_bytes() / 2 ** 20, 1), "output_finite": finite,
             "pcie_inclusive_value": None if pcie_value is None else round(pcie_value, 2),
-            "roofline": roofline, "roofline_attention": roofline_attn,
+            "roofline": roofline, "roofline_attention": roofline_attn, "roofline_hbm": roofline_hbm,
         }
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(kwargs, T, S, args.cpu_threads)
+            line["cpu_baseline"] = cpu_baseline(kwargs, T, (SH, SW), args.cpu_threads)
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
@@ -240,51 +291,97 @@ def main():
         dist.destroy_process_group()
 
 
-def train_bench(args, model, x, dev, rank, world, kwargs, sync_all):
-    """One fine-tune step per iteration: HIP forward keeping activations, a PyTorch loss on the four disparity maps (the
-    reference's losses stay PyTorch, north_star), HIP backward to the LoRA factors, ONE all-reduce of the flat gradient
-    buffer, AdamW.  One clip per GPU per step (the reference's DataParallel split, trainer_end_to_end_video.py:731)."""
+def train_bench(args, model, x, dev, rank, world, kwargs):
+    """One fine-tune step per iteration: HIP forward keeping activations, the photometric loss on the four disparity maps in PyTorch (the
+    reference's losses stay PyTorch, north_star: endodav_amd/losses.py restates utils/layers.py's SSIM / back-projection / smoothness and
+    the trainer's per-scale sum), HIP backward into ONE flat gradient buffer, ONE in-place all-reduce of it, AdamW.  One clip per GPU per
+    step (the reference's DataParallel split, trainer_end_to_end_video.py:731)."""
     import torch
     import torch.distributed as dist
 
     import endodav_amd
-    from endodav_amd import parallel
+    from endodav_amd import losses, parallel
 
     endodav_amd.mark_only_part_as_trainable(model, warm_up=True)
+    model.train()
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(params, lr=1e-4)
-    T, S = args.T, args.image
+    T, (SH, SW) = args.T, args.image_hw
+    frames = x.flatten(0, 1)  # [B*T, 3, H, W]: the loss compares each frame with its warped neighbours at the frame size
+    cams = [losses.synthetic_camera(T, frames.shape[-2], frames.shape[-1], dev) for _ in range(args.clips)]
+    events = not args.no_kernel_events
+    lin_from = args.steps - min(LIN_STEPS, args.steps)
+    state = {}
+    loss_ms = []
 
-    def step():
+    def loss_fn(out):
+        if args.l1_loss:
+            return sum((o - o.detach().mean()).abs().mean() for o in out.values())
+        total = 0.0
+        for b in range(args.clips):
+            sl = slice(b * T, (b + 1) * T)
+            K, inv_K, Tp, Tn = cams[b]
+            total = total + losses.photometric_loss({k: v[sl] for k, v in out.items()}, frames[sl], K, inv_K, Tp, Tn)
+        return total / args.clips
+
+    def step(i):
+        if i == lin_from and events:
+            model.profile_set(["linear"])
+        timed = events and i >= lin_from
         opt.zero_grad(set_to_none=True)
         out = model(x)
-        loss = sum((o - o.detach().mean()).abs().mean() for o in out.values())  # stand-in for the photometric loss: an L1 on every scale
+        if timed:
+            e0, e1, e2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        loss = loss_fn(out)
+        if timed:
+            e1.record()
         loss.backward()
-        n = parallel.allreduce_gradients(params)
+        if timed:
+            e2.record()
+            state.setdefault("ev", []).append((e0, e1, e2))
+        state["n"] = parallel.allreduce_gradients(params, model=model)
         opt.step()
-        return loss, n
+        state["loss"] = loss
 
-    for _ in range(max(args.warmup, 1)):
-        loss, nred = step()
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, nred = step()
-    torch.cuda.synchronize(dev)
-    parallel.barrier()
-    dt = parallel.max_over_ranks(time.perf_counter() - t0, dev)
+    model(x)  # creates the context
+    model.profile_enable([])
+    dt, _ = parallel.timed_region(step, args.steps, max(args.warmup, 1), dev)
+    roofline = loss_share = None
+    if events:
+        n_h, ms_h = model.profile_read("linear")
+        fl_h, by_h = model.profile_work("linear")
+        n_e, ms_e = model.profile_read("linear_encoder")
+        fl_e, by_e = model.profile_work("linear_encoder")
+        n_l, ms_l, fl_l = n_h + n_e, ms_h + ms_e, fl_h + fl_e
+        if n_l > 0 and ms_l > 0:
+            ach = fl_l / (ms_l * 1e-3) / 1e12
+            roofline = {"kernel": "gemm_dma_kernel (every dense GEMM of the step: the forward's F.linear / 1x1 convs and the backward's input-gradient GEMMs)",
+                        "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4),
+                        "traffic": None, "launches": n_l, "avg_launch_ms": round(ms_l / n_l, 4), "flop_per_launch": round(fl_l / n_l, 1),
+                        "algorithmic_bytes_per_launch": round((by_h + by_e) / n_l, 1), "ms_per_step": round(ms_l / LIN_STEPS, 3),
+                        "peak_dtype": "f32 MFMA (v_mfma_f32_32x32x2_f32), dense"}
+        if state.get("ev"):
+            fw = [a.elapsed_time(b) for a, b, _ in state["ev"]]
+            bw = [b.elapsed_time(c) for _, b, c in state["ev"]]
+            loss_share = {"loss_forward_ms": round(statistics.mean(fw), 3), "loss_backward_plus_hip_backward_ms": round(statistics.mean(bw), 3),
+                          "note": "torch.cuda events on the caller's stream in the bracketed steps: loss forward alone; autograd's backward of the loss and "
+                                  "edv_backward together"}
     if rank == 0:
-        frames = world * args.clips * T * args.steps
+        frames_n = world * args.clips * T * args.steps
+        loss_name = "L1 stand-in" if args.l1_loss else "photometric loss (0.85 SSIM + 0.15 L1 on the two warped neighbours + edge-aware smoothness, 4 scales)"
         line = {
-            "metric": f"fine-tune frames/sec ({S}x{S}, T={T} clip, LoRA factors trainable)", "value": round(frames / dt, 2), "unit": "frames/s",
+            "metric": f"fine-tune frames/sec ({SH}x{SW}, T={T} clip, LoRA factors trainable)", "value": round(frames_n / dt, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"ViT-{args.encoder[-1].upper()} endodav fine-tune step ({args.lora}{' + temporal_lora' if args.temporal_lora else ''} r=4, {'conv head, conv_depth_* trainable' if args.conv_head else 'VDA head'}): forward + L1 stand-in loss + HIP "
-                                   f"backward + gradient all-reduce + AdamW, {args.clips} synthetic {S}x{S} T={T} clip(s) per GPU per step",
-                       "encoder": args.encoder, "T": T, "image": [S, S], "clips_per_gpu_per_step": args.clips,
-                       "parallelism": f"data-parallel x{world}: one all-reduce of {nred} gradient floats per step"},
-            "trainable_floats": nred, "loss": float(loss.item()), "device_mem_mb": round(model.device_bytes() / 2 ** 20, 1),
-            "roofline": None, "cpu_baseline": None,
+            "config": {"workload": f"ViT-{args.encoder[-1].upper()} endodav fine-tune step ({args.lora}{' + temporal_lora' if args.temporal_lora else ''} r=4, "
+                                   f"{'conv head, conv_depth_* trainable' if args.conv_head else 'VDA head'}): forward + {loss_name} + HIP backward + gradient "
+                                   f"all-reduce + AdamW, {args.clips} synthetic clip(s) of T={T} {x.shape[-2]}x{x.shape[-1]} frames -> image_shape {SH}x{SW} per GPU per step",
+                       "encoder": args.encoder, "T": T, "image": [SH, SW], "clips_per_gpu_per_step": args.clips,
+                       "parallelism": f"data-parallel x{world}: one in-place all-reduce of the flat gradient buffer ({state['n']} gradient floats) per step"},
+            "trainable_floats": state["n"], "loss": float(state["loss"].item()), "device_mem_mb": round(model.device_bytes() / 2 ** 20, 1),
+            "gradients_in_flat_buffer": model.flat_gradients(params) is not None,
+            "roofline": roofline, "loss_share": loss_share, "cpu_baseline": None,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -11,7 +11,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EDV_LIB_PATH") or os.path.join(_HERE, "lib", "libendodav_hip.so")  # override: experiments only
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 LORA_TYPES = {"none": 0, "lora": 1, "dvlora": 2, "ssb": 3, "dash": 4}
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_SIGMOID_NEG = 0, 1, 2, 3, 4
@@ -83,7 +83,9 @@ SIGNATURES = {
     "edv_attn_spatial": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _fp, C.c_size_t, _fp, C.c_void_p]),
     "edv_set_train": (C.c_int, [C.c_void_p, _i32]),
     "edv_set_grad_scope": (C.c_int, [C.c_void_p, _i32, _i32, _i32, _i32]),
-    "edv_backward": (C.c_int, [C.c_void_p, _fp, C.POINTER(C.c_void_p), C.c_void_p]),
+    "edv_generation": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint64)]),
+    "edv_backward": (C.c_int, [C.c_void_p, C.c_uint64, _fp, C.POINTER(C.c_void_p), C.c_void_p]),
+    "edv_grad_bind_flat": (C.c_int, [C.c_void_p, _i32, C.POINTER(C.c_char_p), C.POINTER(_i64), _fp, _i64, C.POINTER(_i64)]),
     "edv_grad": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(_i64)]),
     "edv_grad_copy": (C.c_int, [C.c_void_p, C.c_char_p, _fp, _i64, C.c_void_p]),
     "edv_attn_spatial_bwd_workspace": (C.c_size_t, [_i32, _i32, _i32]),
@@ -122,7 +124,9 @@ SIGNATURES = {
 
 # "linear_encoder" (the F.linear launches of the encoder blocks) is recorded whenever "linear" is enabled and read separately;
 # "linear" then holds the remaining F.linear / 1x1-conv launches (patch embed, DPT head)
-KERNEL_CLASSES = {"linear": 0, "conv3x3": 1, "attn_spatial": 2, "attn_temporal": 3, "layernorm": 4, "other": 5, "linear_encoder": 6}
+KERNEL_CLASSES = {"linear": 0, "conv3x3": 1, "attn_spatial": 2, "attn_temporal": 3, "layernorm": 4, "other": 5, "linear_encoder": 6,
+                  "groupnorm": 7, "bilinear": 8, "geglu": 9, "dot_channels": 10, "patchify": 11}
+HBM_CLASSES = ("layernorm", "groupnorm", "bilinear", "geglu", "dot_channels", "patchify")  # bandwidth-bound kernels (bench.py roofline_hbm)
 
 
 class EdvError(RuntimeError):

@@ -47,7 +47,10 @@ struct Buf {
 // with the same mask bit as KC_LINEAR and reported separately (the head's small GEMMs are HBM- and launch-bound, not MFMA-bound)
 constexpr int PE_K = 608;  // patch-embed im2col width 3 * 14 * 14 = 588, padded to a multiple of 32
 
-enum { KC_LINEAR = 0, KC_CONV3 = 1, KC_ATTN_SPATIAL = 2, KC_ATTN_TEMPORAL = 3, KC_NORM = 4, KC_OTHER = 5, KC_LINEAR_ENC = 6, KC_COUNT = 7 };
+// KC_GROUPNORM .. KC_PATCHIFY: the HBM-bound kernels of the forward, each with its algorithmic bytes (tensor in + tensor out, once) for
+// bench.py's roofline_hbm object
+enum { KC_LINEAR = 0, KC_CONV3 = 1, KC_ATTN_SPATIAL = 2, KC_ATTN_TEMPORAL = 3, KC_NORM = 4, KC_OTHER = 5, KC_LINEAR_ENC = 6, KC_GROUPNORM = 7,
+       KC_BILINEAR = 8, KC_GEGLU = 9, KC_DOT = 10, KC_PATCHIFY = 11, KC_COUNT = 12 };
 struct EvPool {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     size_t used = 0;
@@ -57,8 +60,8 @@ struct edv_ctx {
     edv_config cfg{};
     unsigned prof_mask = 0;
     EvPool prof[KC_COUNT];
-    double prof_flops[KC_COUNT] = {0, 0, 0, 0, 0, 0, 0};  // algorithmic work of the bracketed launches (edv_profile_work)
-    double prof_bytes[KC_COUNT] = {0, 0, 0, 0, 0, 0, 0};
+    double prof_flops[KC_COUNT] = {};  // algorithmic work of the bracketed launches (edv_profile_work)
+    double prof_bytes[KC_COUNT] = {};
     int enc_streams = 0;                      // 0: automatic (2 for small clips); n >= 1: that many frame groups on internal streams
     int enc_streams_initial = 0;              // what EDV_ENC_STREAMS asked for at edv_create (edv_set_encoder_streams(-1) restores it)
     hipStream_t sub[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -78,6 +81,18 @@ struct edv_ctx {
     bool grad_res = false;        // parameters of the residual bottleneck blocks (residual_*, trainable by default in the reference)
     bool grad_head = false;       // weight / bias gradients of the output-head convolutions (conv_depth_*, or scratch.output_conv* with --train_output_conv)
     std::unordered_map<std::string, Buf> grads;  // gradients of the trainable parameters, owned
+    // Caller-owned flat gradient buffer (edv_grad_bind_flat): a gradient whose name is listed here is written straight into its slice
+    // of that buffer instead of into `grads` -- the host's .grad tensors are views of it and the data-parallel all-reduce runs on
+    // it in place (trainer_end_to_end_video.py:269-271's reduce), with no per-tensor copy on either side.
+    struct FlatSlot {
+        float *p;
+        size_t numel;
+        bool written;
+    };
+    std::unordered_map<std::string, FlatSlot> flat;
+    int device = 0;                 // HIP device the context was created on (edv_destroy frees there)
+    uint64_t generation = 0;        // counts training forwards; the kept activations belong to forward number `saved_generation`
+    uint64_t saved_generation = 0;
     int launches = 0;
     size_t bytes = 0;
     // geometry of the last forward (for edv_stage_copy)
@@ -126,6 +141,14 @@ struct Bracket {
     }
     ~Bracket() {
         if (stop) (void)hipEventRecord(stop, st);
+    }
+};
+
+// Bracket for a bandwidth-bound launch: also books its algorithmic bytes (every tensor it reads or writes, once)
+struct HbmScope {
+    Bracket b;
+    HbmScope(edv_ctx *c, int cls, hipStream_t st, double bytes) : b(c, cls, st) {
+        if (c->prof_mask & (1u << cls)) c->prof_bytes[cls] += bytes;
     }
 };
 
@@ -200,6 +223,10 @@ struct Run {
         g.bias = bias; g.act = act; g.R1 = R1; g.ldr1 = Cout; g.R2 = R2; g.ldr2 = Cout;
         g.loader = LOAD_CONV3; g.cH = H; g.cW = W; g.cC = Cin; g.cOH = OH; g.cOW = OW; g.cS = stride; g.pre_relu = pre_relu ? 1 : 0;
         c->launches++;
+        if (c->prof_mask & (1u << KC_CONV3)) {  // 2 M N K; input and output tensors once, the packed weight once
+            c->prof_flops[KC_CONV3] += 2.0 * (double)g.M * g.N * g.K;
+            c->prof_bytes[KC_CONV3] += 4.0 * ((double)F * H * W * Cin + (double)g.N * g.K + (double)g.M * g.N * (1 + (R1 ? 1 : 0) + (R2 ? 1 : 0)));
+        }
         Bracket b_(c, KC_CONV3, st);
         return gemm_ws(g);
     }
@@ -209,7 +236,7 @@ struct Run {
         EDV_TRY(param(prefix + ".weight", &w));
         EDV_TRY(param(prefix + ".bias", &b));
         c->launches++;
-        Bracket b_(c, KC_NORM, st);
+        HbmScope b_(c, KC_NORM, st, 8.0 * (double)rows * dim);
         return layernorm(x, im, w, b, y, identity_map(), rows, dim, eps, pe, rpf, TT, st);
     }
 
@@ -485,7 +512,10 @@ struct Run {
             gnpart_n = groupnorm_workspace(F, P, C);
             EDV_TRY(wsbuf(sc_ + "gnpart", gnpart_n, &gnpart));
         }
-        EDV_TRY(groupnorm(xin, w, b, gn, stats, F, P, C, 32, 1e-6f, st, gnpart, gnpart_n));
+        {
+            HbmScope b_(c, KC_GROUPNORM, st, 8.0 * (double)M * C);  // statistics + apply, 2-3 launches
+            EDV_TRY(groupnorm(xin, w, b, gn, stats, F, P, C, 32, 1e-6f, st, gnpart, gnpart_n));
+        }
         c->launches += 2;
         EDV_TRY(param(p + ".proj_in.weight", &w));
         EDV_TRY(param(p + ".proj_in.bias", &b));
@@ -517,7 +547,10 @@ struct Run {
         EDV_TRY(param(tb + ".ff.net.0.proj.weight", &w));
         EDV_TRY(param(tb + ".ff.net.0.proj.bias", &b));
         EDV_TRY(linear(hn, M, C, w, 8 * C, b, ff1));
-        EDV_TRY(geglu(ff1, ff2, M, 4 * C, st));
+        {
+            HbmScope b_(c, KC_GEGLU, st, 4.0 * (double)M * 12 * C);
+            EDV_TRY(geglu(ff1, ff2, M, 4 * C, st));
+        }
         c->launches++;
         EDV_TRY(lin_w(tb + ".ff.net.2", &w));
         EDV_TRY(param(tb + ".ff.net.2.bias", &b));
@@ -576,7 +609,10 @@ struct Run {
         EDV_TRY(param(p + ".out_conv.weight", &wo));
         EDV_TRY(param(p + ".out_conv.bias", &bo));
         EDV_TRY(linear(t2, (long long)F * h * w, Fe, wo, Fe, bo, t1));
-        EDV_TRY(bilinear(t1, out, F, h, w, Fe, oh, ow, ACT_NONE, st));
+        {
+            HbmScope b_(c, KC_BILINEAR, st, 4.0 * (double)F * Fe * ((double)h * w + (double)oh * ow));
+            EDV_TRY(bilinear(t1, out, F, h, w, Fe, oh, ow, ACT_NONE, st));
+        }
         c->launches++;
         return 0;
     }
@@ -612,7 +648,10 @@ struct Run {
         EDV_TRY(param(p + ".out_conv.weight", &wo));
         EDV_TRY(param(p + ".out_conv.bias", &bo));
         EDV_TRY(linear(t2, (long long)F * h * w, Fe, wo, Fe, bo, t1));
-        EDV_TRY(bilinear(t1, out, F, h, w, Fe, oh, ow, ACT_NONE, st, add));
+        {
+            HbmScope b_(c, KC_BILINEAR, st, 4.0 * (double)F * Fe * ((double)h * w + (double)oh * ow * (add ? 2 : 1)));
+            EDV_TRY(bilinear(t1, out, F, h, w, Fe, oh, ow, ACT_NONE, st, add));
+        }
         c->launches++;
         return 0;
     }
@@ -815,7 +854,10 @@ struct Run {
         const float *pos = eb.pos;
         rb_suffix = "." + std::to_string(f0);
         if (c->train) EDV_TRY(trainbuf("t.x.0", (size_t)ntok * D, &xt));  // block i reads t.x.i and writes t.xmid.i, t.x.(i+1)
-        EDV_TRY(patchify(x + (size_t)f0 * 3 * H * W, cols, F, H, W, cfg.image_h, cfg.image_w, st, PE_K));
+        {
+            HbmScope b_(c, KC_PATCHIFY, st, 4.0 * (double)F * (3.0 * H * W + (double)P0 * PE_K));
+            EDV_TRY(patchify(x + (size_t)f0 * 3 * H * W, cols, F, H, W, cfg.image_h, cfg.image_w, st, PE_K));
+        }
         c->launches++;
         {
             const float *w, *b;
@@ -997,7 +1039,7 @@ struct Run {
                 stagger_record = stagger && h + 1 < nstreams;
                 const int rc = encoder_range(eb, x, f0, nf, H, W, c->sub[h], h);
                 st = user; F = Fall; skws = skws_all;
-                if (rc) return rc;
+                if (rc) return rc;  // edv_forward waits for the internal streams before it reports the error
                 EDV_HIP(hipEventRecord(c->ev_join[h], c->sub[h]));
                 EDV_HIP(hipStreamWaitEvent(user, c->ev_join[h], 0));
                 f0 += nf;
@@ -1125,7 +1167,7 @@ struct Run {
             st = side; skws = ws_side;
             int rc = level(3);
             st = user; skws = ws_user;
-            if (rc) return rc;
+            if (rc) return rc;  // edv_forward waits for the internal streams before it reports the error
             EDV_HIP(hipEventRecord(c->ev_join[0], side));     // r4 ready
             EDV_TRY(level(2));
             if (cfg.conv_head) {  // the four HeadDepth heads read path_4..path_1 themselves: no folding of u into them
@@ -1144,7 +1186,7 @@ struct Run {
                 st = side; skws = ws_side;
                 rc = fusion_skip_branch(3, r3, h3, w3, u3);
                 st = user; skws = ws_user;
-                if (rc) return rc;
+                if (rc) return rc;  // edv_forward waits for the internal streams before it reports the error
                 EDV_HIP(hipEventRecord(c->ev_x[2], side));        // u3 ready
                 EDV_TRY(level(0));
                 EDV_TRY(level(1));
@@ -1155,7 +1197,7 @@ struct Run {
                 if (!rc) EDV_HIP(hipEventRecord(c->ev_x[3], side));  // u2 ready
                 if (!rc) rc = fusion_skip_branch(1, r1, h1, w1, u1);
                 st = user; skws = ws_user;
-                if (rc) return rc;
+                if (rc) return rc;  // edv_forward waits for the internal streams before it reports the error
                 EDV_HIP(hipEventRecord(c->ev_x[4], side));        // u1 ready
                 EDV_HIP(hipStreamWaitEvent(user, c->ev_join[0], 0));
                 EDV_TRY(fusion(4, r4, nullptr, h4, w4, h3, w3, p4));
@@ -1195,16 +1237,23 @@ struct Run {
             EDV_TRY(packedw("head.scratch.output_conv1.weight", &w));
             EDV_TRY(param("head.scratch.output_conv1.bias", &b));
             EDV_TRY(conv3(p1, h0, w0, Fe, w, b, Fh, 1, o1, false));
-            EDV_TRY(bilinear(o1, up, F, h0, w0, Fh, ih, iw, ACT_NONE, st));
+            {
+                HbmScope b_(c, KC_BILINEAR, st, 4.0 * (double)F * Fh * ((double)h0 * w0 + (double)ih * iw));
+                EDV_TRY(bilinear(o1, up, F, h0, w0, Fh, ih, iw, ACT_NONE, st));
+            }
             EDV_TRY(packedw("head.scratch.output_conv2.0.weight", &w));
             EDV_TRY(param("head.scratch.output_conv2.0.bias", &b));
             EDV_TRY(conv3(up, ih, iw, Fh, w, b, 32, 1, o2, false, ACT_RELU));
             EDV_TRY(param("head.scratch.output_conv2.2.weight", &w));
             EDV_TRY(param("head.scratch.output_conv2.2.bias", &b));
-            EDV_TRY(dot_channels(o2, w, b, disp[0], (long long)F * ih * iw, 32, ACT_RELU, st));
+            {
+                HbmScope b_(c, KC_DOT, st, 4.0 * (double)F * ih * iw * 33);
+                EDV_TRY(dot_channels(o2, w, b, disp[0], (long long)F * ih * iw, 32, ACT_RELU, st));
+            }
             int sh = ih, sw = iw;
             for (int k = 1; k < 4; ++k) {  // F.interpolate(scale_factor=0.5): floor(in/2)
                 const int nh = sh / 2, nw = sw / 2;
+                HbmScope b_(c, KC_BILINEAR, st, 4.0 * (double)F * ((double)sh * sw + (double)nh * nw));
                 EDV_TRY(bilinear(disp[k - 1], disp[k], F, sh, sw, 1, nh, nw, ACT_NONE, st));
                 sh = nh; sw = nw;
             }
@@ -1244,13 +1293,19 @@ struct Run {
                 EDV_TRY(packedw(hp + "0.weight", &w));
                 EDV_TRY(param(hp + "0.bias", &b));
                 EDV_TRY(conv3(paths[k], hs[k], wsz[k], Fe, w, b, Fh, 1, o1, false));
-                EDV_TRY(bilinear(o1, up, F, hs[k], wsz[k], Fh, 2 * hs[k], 2 * wsz[k], ACT_NONE, st));
+                {
+                    HbmScope b_(c, KC_BILINEAR, st, 4.0 * (double)F * Fh * 5.0 * hs[k] * wsz[k]);
+                    EDV_TRY(bilinear(o1, up, F, hs[k], wsz[k], Fh, 2 * hs[k], 2 * wsz[k], ACT_NONE, st));
+                }
                 EDV_TRY(packedw(hp + "2.weight", &w));
                 EDV_TRY(param(hp + "2.bias", &b));
                 EDV_TRY(conv3(up, 2 * hs[k], 2 * wsz[k], Fh, w, b, 32, 1, o2, false, ACT_RELU));
                 EDV_TRY(param(hp + "4.weight", &w));
                 EDV_TRY(param(hp + "4.bias", &b));
-                EDV_TRY(dot_channels(o2, w, b, disp[k], (long long)px * 4, 32, cfg.inv_sigmoid ? ACT_SIGMOID_NEG : ACT_SIGMOID, st));
+                {
+                    HbmScope b_(c, KC_DOT, st, 4.0 * (double)px * 4 * 33);
+                    EDV_TRY(dot_channels(o2, w, b, disp[k], (long long)px * 4, 32, cfg.inv_sigmoid ? ACT_SIGMOID_NEG : ACT_SIGMOID, st));
+                }
                 c->launches += 2;
                 if (c->train) {
                     float *dk;
@@ -1268,7 +1323,17 @@ struct Run {
     // contributes its input gradient only.  Mirrors forward() in reverse on the activations a training forward kept.
     float *lora_ws = nullptr;  // workspace of lora_grads for the whole backward
     size_t lora_ws_n = 0;
-    int gradbuf(const std::string &name, size_t n, float **out) { return alloc_buf(c, c->grads, name, n, st, out); }
+    int gradbuf(const std::string &name, size_t n, float **out) {
+        auto it = c->flat.find(name);
+        if (it != c->flat.end()) {  // the caller's flat buffer holds this gradient (edv_grad_bind_flat)
+            EDV_CHECK(it->second.numel == n, "flat gradient slice of " + name + " has " + std::to_string(it->second.numel) + " floats, the gradient " +
+                                                 std::to_string(n));
+            it->second.written = true;
+            *out = it->second.p;
+            return 0;
+        }
+        return alloc_buf(c, c->grads, name, n, st, out);
+    }
     int saved(const std::string &name, const float **out) {
         auto it = c->ws.find(name);
         EDV_CHECK(it != c->ws.end() && it->second.p, "activation not saved (run a forward with edv_set_train first): " + name);
@@ -1500,7 +1565,8 @@ struct Run {
     }
 
     int backward(const float *disp0, const float *const g[4]) {
-        EDV_CHECK(c->train && c->have_saved, "edv_backward needs a forward run under edv_set_train(1)");
+        EDV_CHECK(c->train && c->have_saved, "edv_backward needs the activations of a forward run under edv_set_train(1): none are kept (no such forward yet, "
+                                             "a backward already consumed them, or an inference forward on this context ran in between)");
         if (!c->train_prepared) EDV_TRY(prepare_train());
         B = c->F / c->T; T = c->T; F = c->F; ph = c->ph; pw = c->pw; P0 = ph * pw;
         c0 = cfg.include_cls_token ? 1 : 0;
@@ -1849,12 +1915,18 @@ int edv_create(const edv_config *cfg, edv_ctx **out) {
     for (int j = 0; j < 4; ++j) EDV_CHECK(cfg->taps[j] >= 0 && cfg->taps[j] < cfg->depth && (j == 0 || cfg->taps[j] > cfg->taps[j - 1]), "taps");
     *out = new edv_ctx();
     (*out)->cfg = *cfg;
+    if (hipGetDevice(&(*out)->device) != hipSuccess) (*out)->device = -1;  // no device visible (host-only checks of the configuration)
     if (const char *e = getenv("EDV_ENC_STREAMS")) (*out)->enc_streams = (*out)->enc_streams_initial = atoi(e);
     return 0;
 }
 
 int edv_destroy(edv_ctx *ctx) {
     if (!ctx) return 0;
+    // free on the device the context lives on, whatever device the calling thread has current (nn.DataParallel destroys replicas'
+    // contexts from the main thread), and give the caller its device back
+    int cur = -1;
+    (void)hipGetDevice(&cur);
+    if (ctx->device >= 0 && cur != ctx->device) (void)hipSetDevice(ctx->device);
     (void)hipDeviceSynchronize();
     for (auto &kv : ctx->packed)
         if (kv.second.p) (void)hipFree(kv.second.p);
@@ -1874,7 +1946,9 @@ int edv_destroy(edv_ctx *ctx) {
             (void)hipEventDestroy(e.first);
             (void)hipEventDestroy(e.second);
         }
+    const int dev = ctx->device;
     delete ctx;
+    if (dev >= 0 && cur >= 0 && cur != dev) (void)hipSetDevice(cur);
     return 0;
 }
 
@@ -1913,6 +1987,10 @@ int edv_forward(edv_ctx *ctx, const float *x_dev, int32_t B, int32_t T, int32_t 
     EDV_CHECK(B > 0 && T > 0 && H > 1 && W > 1, "empty clip");
     // motion_module.py:197: the position table is sliced to T -> size mismatch beyond num_frames
     EDV_CHECK(T <= ctx->cfg.num_frames, "T exceeds num_frames (temporal_max_len)");
+    // narrower than the reference, which takes any T <= num_frames: the temporal-attention kernels hold one clip's T x T scores per
+    // pixel on chip and are built for T <= 32 = the reference's own INFER_LEN and num_frames default (endodav.py:47, :62)
+    EDV_CHECK(T <= 32, "T > 32 frames per clip is not built (the reference's window length and num_frames default are 32)");
+
     EDV_CHECK((long long)B * T <= 65535, "too many frames in one call");
     for (int k = 0; k < 4; ++k) EDV_CHECK(disp_dev[k], "null output");
     if (ctx->train) {
@@ -1920,9 +1998,26 @@ int edv_forward(edv_ctx *ctx, const float *x_dev, int32_t B, int32_t T, int32_t 
         EDV_CHECK(!ctx->capture, "stage capture and training are exclusive");
     }
     Run r(ctx, (hipStream_t)stream);
+    if (ctx->train) ++ctx->generation;  // the kept activations are about to be overwritten
     const int rc = r.forward(x_dev, B, T, H, W, disp_dev);
+    if (rc && ctx->sub[0]) {
+        // The error may have struck between a fork and its join: kernels already enqueued on the internal streams still write the
+        // shared workspaces, and nothing makes the caller's stream wait for them.  Drain them before reporting, so that whatever the
+        // caller enqueues next (another edv_forward on this context included) cannot overlap them.
+        const std::string msg = edv::get_error();
+        for (int h = 0; h < 4; ++h)
+            if (ctx->sub[h]) (void)hipStreamSynchronize(ctx->sub[h]);
+        edv::set_error(msg);
+    }
     ctx->have_saved = rc == 0 && ctx->train;
+    if (ctx->have_saved) ctx->saved_generation = ctx->generation;
     return rc;
+}
+
+int edv_generation(const edv_ctx *ctx, uint64_t *generation) {
+    EDV_CHECK(ctx && generation, "null argument");
+    *generation = ctx->generation;
+    return 0;
 }
 
 int edv_set_train(edv_ctx *ctx, int32_t on) {
@@ -1948,11 +2043,37 @@ int edv_set_grad_scope(edv_ctx *ctx, int32_t encoder_factors, int32_t temporal_f
     return 0;
 }
 
-int edv_backward(edv_ctx *ctx, const float *disp0_dev, const float *const grad_disp_dev[4], void *stream) {
+int edv_backward(edv_ctx *ctx, uint64_t generation, const float *disp0_dev, const float *const grad_disp_dev[4], void *stream) {
     EDV_CHECK(ctx && disp0_dev && grad_disp_dev, "null argument");
     for (int k = 0; k < 4; ++k) EDV_CHECK(grad_disp_dev[k], "null gradient");
+    // One set of kept activations per context: a second training forward overwrites them, and a backward of the first forward's graph
+    // would then silently differentiate the second clip.  The caller names the forward it is differentiating.
+    EDV_CHECK(generation == 0 || !ctx->have_saved || generation == ctx->saved_generation,
+              "edv_backward for training forward #" + std::to_string(generation) + ", but the kept activations are those of forward #" +
+                  std::to_string(ctx->saved_generation) + ": a later grad-enabled forward on this context overwrote them (one backward per forward)");
+    for (auto &kv : ctx->flat) kv.second.written = false;
     Run r(ctx, (hipStream_t)stream);
-    return r.backward(disp0_dev, grad_disp_dev);
+    const int rc = r.backward(disp0_dev, grad_disp_dev);
+    if (rc) return rc;
+    for (auto &kv : ctx->flat)
+        EDV_CHECK(kv.second.written, "the flat gradient buffer lists " + kv.first + ", but this backward produced no gradient for it (edv_set_grad_scope)");
+    return 0;
+}
+
+int edv_grad_bind_flat(edv_ctx *ctx, int32_t n, const char *const *names, const int64_t *numels, float *flat_dev, int64_t flat_floats, int64_t *offsets_out) {
+    EDV_CHECK(ctx && n >= 0 && (n == 0 || (names && numels && offsets_out)), "bad argument");
+    int64_t off = 0;
+    for (int i = 0; i < n; ++i) {
+        EDV_CHECK(names[i] && numels[i] > 0, "bad slice");
+        offsets_out[i] = off;
+        off += (numels[i] + 3) & ~(int64_t)3;  // every slice starts on a 16-byte boundary (float4 stores of the reduction kernels)
+    }
+    if (n) offsets_out[n] = off;
+    if (!flat_dev) return 0;  // layout query
+    EDV_CHECK(flat_floats >= off && (uintptr_t)flat_dev % 16 == 0, "flat gradient buffer too small or not 16-byte aligned");
+    ctx->flat.clear();
+    for (int i = 0; i < n; ++i) ctx->flat[names[i]] = edv_ctx::FlatSlot{flat_dev + offsets_out[i], (size_t)numels[i], false};
+    return 0;
 }
 
 int edv_grad_copy(edv_ctx *ctx, const char *name, float *dst_dev, int64_t numel, void *stream) {

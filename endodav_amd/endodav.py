@@ -357,6 +357,7 @@ class _NativeCtx:
 
     def __init__(self, handle: int, device: torch.device):
         self.handle, self.device, self.sig = handle, device, None
+        self.flat: Optional["_FlatGrads"] = None
 
     def __del__(self):
         try:
@@ -365,19 +366,61 @@ class _NativeCtx:
             pass
 
 
+class _FlatGrads:
+    """ONE contiguous device buffer that receives every trainable gradient of a context (``edv_grad_bind_flat``): the engine
+    writes each gradient into its slice, ``p.grad`` is a view of that slice, and the data-parallel all-reduce runs on the whole
+    buffer in place (``parallel.allreduce_gradients``) -- no per-tensor copy anywhere in the step.  Rebuilt when the trainable
+    set changes (the freeze schedule switches A/B -> U/V after the warm-up, trainer_end_to_end_video.py:324-339)."""
+
+    def __init__(self, nat: _NativeCtx, names: Tuple[str, ...], shapes: Sequence[Tuple[int, ...]]):
+        lib = _lib.load()
+        n = len(names)
+        self.names, self.shapes = names, [tuple(s) for s in shapes]
+        self._c_names = (C.c_char_p * n)(*[k.encode() for k in names])
+        self._c_numels = (C.c_int64 * n)(*[int(np.prod(s)) if len(s) else 1 for s in shapes])
+        offs = (C.c_int64 * (n + 1))()
+        _lib.check(lib.edv_grad_bind_flat(C.c_void_p(nat.handle), n, self._c_names, self._c_numels, None, 0, offs), "edv_grad_bind_flat (layout)")
+        self.offsets = list(offs)[:n]
+        self.flat = torch.zeros(int(offs[n]), device=nat.device, dtype=torch.float32)  # the padding between slices stays zero
+        _lib.check(lib.edv_grad_bind_flat(C.c_void_p(nat.handle), n, self._c_names, self._c_numels, self.flat.data_ptr(), self.flat.numel(), offs),
+                   "edv_grad_bind_flat")
+
+    def views(self, flat: Optional[torch.Tensor] = None) -> List[torch.Tensor]:
+        """Fresh view tensors of the slices of ``flat`` (default: the bound buffer).  Fresh, so that autograd's AccumulateGrad may
+        adopt them as ``.grad`` without a copy: it does so only for a gradient tensor nobody else references."""
+        flat = self.flat if flat is None else flat
+        out = []
+        for off, shp in zip(self.offsets, self.shapes):
+            st, acc = [], 1
+            for d in reversed(shp):
+                st.append(acc)
+                acc *= d
+            out.append(flat.as_strided(shp, tuple(reversed(st)), off))
+        return out
+
+    def aliases(self, i: int, t: Optional[torch.Tensor]) -> bool:
+        return t is not None and t.data_ptr() == self.flat.data_ptr() + 4 * self.offsets[i] and t.is_contiguous() and tuple(t.shape) == self.shapes[i]
+
+
 # ---------------------------------------------------------------------------------------------
 class _EdvFunction(torch.autograd.Function):
     """One training step through libendodav_hip: ``edv_forward`` under ``edv_set_train`` keeps the activations,
-    ``edv_backward`` turns dL/d("disp", 0..3) into the gradients of the LoRA factors (trainer_end_to_end_video.py:731,
-    :427-431).  The factors are passed as inputs only so that autograd routes their gradients."""
+    ``edv_backward`` turns dL/d("disp", 0..3) into the gradients of the trainable tensors (trainer_end_to_end_video.py:731,
+    :427-431).  The tensors are passed as inputs only so that autograd routes their gradients.
+
+    A context keeps ONE set of activations: the forward records the context's generation and the backward hands it back, so a
+    backward whose activations a later grad-enabled forward has overwritten raises instead of differentiating the wrong clip."""
 
     @staticmethod
     def forward(ctx, model, x, names, *params):
         outs = model._run_native(x, train=True)
         ctx.model, ctx.names, ctx.device = model, names, x.device
-        ctx.handle = model._last.handle
+        ctx.nat = model._last
+        gen = C.c_uint64()
+        _lib.check(_lib.load().edv_generation(C.c_void_p(ctx.nat.handle), C.byref(gen)), "edv_generation")
+        ctx.generation = gen.value
         ctx.shapes = [tuple(o.shape) for o in outs]
-        ctx.param_shapes = [tuple(p.shape) for p in params]
+        ctx.params = params
         ctx.save_for_backward(outs[0])
         return tuple(outs)
 
@@ -385,6 +428,7 @@ class _EdvFunction(torch.autograd.Function):
     def backward(ctx, *gouts):
         (disp0,) = ctx.saved_tensors
         lib = _lib.load()
+        nat = ctx.nat
         with torch.cuda.device(ctx.device):
             gs = [(g.detach().contiguous().float() if g is not None else torch.zeros(shp, device=ctx.device)) for g, shp in zip(gouts, ctx.shapes)]
             ptrs = (C.c_void_p * 4)(*[g.data_ptr() for g in gs])
@@ -393,13 +437,26 @@ class _EdvFunction(torch.autograd.Function):
             tmp = any(".ff.net.2." in n for n in ctx.names)
             hd = any(_is_head_conv(n) for n in ctx.names)
             rb = any(".residual_." in n for n in ctx.names)
-            _lib.check(lib.edv_set_grad_scope(C.c_void_p(ctx.handle), int(enc), int(tmp), int(hd), int(rb)), "edv_set_grad_scope")
-            _lib.check(lib.edv_backward(C.c_void_p(ctx.handle), disp0.data_ptr(), ptrs, stream), "edv_backward")
-            grads = []
-            for name, shp in zip(ctx.names, ctx.param_shapes):
-                g = torch.empty(shp, device=ctx.device, dtype=torch.float32)
-                _lib.check(lib.edv_grad_copy(C.c_void_p(ctx.handle), name.encode(), g.data_ptr(), g.numel(), stream), f"edv_grad_copy({name})")
-                grads.append(g)
+            shapes = [tuple(p.shape) for p in ctx.params]
+            fg = nat.flat
+            if fg is None or fg.names != ctx.names or fg.shapes != shapes:
+                fg = nat.flat = _FlatGrads(nat, ctx.names, shapes)
+            # Gradient accumulation (a second backward without zero_grad): a .grad that IS a slice of the flat buffer would be
+            # overwritten by the engine before autograd could add to it.  Keep the old sums and add them back in place.
+            held = [i for i, p in enumerate(ctx.params) if p.is_leaf and fg.aliases(i, p.grad)]
+            prev = fg.flat.clone() if held else None
+            _lib.check(lib.edv_set_grad_scope(C.c_void_p(nat.handle), int(enc), int(tmp), int(hd), int(rb)), "edv_set_grad_scope")
+            _lib.check(lib.edv_backward(C.c_void_p(nat.handle), C.c_uint64(ctx.generation), disp0.data_ptr(), ptrs, stream), "edv_backward")
+            grads: List[Optional[torch.Tensor]] = fg.views()
+            if held:
+                if len(held) == len(grads):
+                    fg.flat.add_(prev)
+                else:
+                    pv = fg.views(prev)
+                    for i in held:
+                        grads[i].add_(pv[i])
+                for i in held:
+                    grads[i] = None  # p.grad already is this slice, and it now holds old + new
         return (None, None, None, *grads)
 
 
@@ -676,6 +733,22 @@ class endodav(nn.Module):
         fl, by = C.c_double(), C.c_double()
         _lib.check(_lib.load().edv_profile_work(C.c_void_p(self._last.handle), _lib.KERNEL_CLASSES[cls], C.byref(fl), C.byref(by)), "edv_profile_work")
         return fl.value, by.value
+
+    def flat_gradients(self, params: Sequence[torch.nn.Parameter]) -> Optional[torch.Tensor]:
+        """The flat gradient buffer of the last backward if ``params`` are exactly the tensors it covers and every ``p.grad`` IS its
+        slice of that buffer (then one in-place all-reduce of the buffer reduces every gradient); None otherwise."""
+        nat = getattr(self, "_last", None)
+        fg = nat.flat if nat is not None else None
+        if fg is None:
+            return None
+        sd = self.state_dict(keep_vars=True)
+        mine = [sd.get(n) for n in fg.names]
+        wanted = {id(p) for p in params if p.requires_grad}
+        if {id(p) for p in mine} != wanted or any(p is None for p in mine):
+            return None
+        if not all(fg.aliases(i, p.grad) for i, p in enumerate(mine)):
+            return None
+        return fg.flat
 
     def device_bytes(self) -> int:
         nat = getattr(self, "_last", None)

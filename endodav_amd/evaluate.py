@@ -103,42 +103,73 @@ def tas(depth_a, mask_a, i2w_a, depth_b, mask_b, i2w_b) -> float:
 
 
 # ---- harness ---------------------------------------------------------------------------------------------------------
-def evaluate_video(depther, dataset: Iterable[dict], *, min_depth: float = 0.1, max_depth: float = 150.0, depth_align: str = "scale",
-                   pred_depth_scale_factor: float = 1.0, eval_max_depth: float = 150.0, device: str = "cuda") -> Dict[str, object]:
-    """The loop of evaluate_depth_video.py:163-215: per clip ``infer_video_depth`` -> depth -> alignment -> per-frame
-    errors and frame-to-frame TAE (x100) / TAS.  ``depther`` only needs ``infer_video_depth(colors)``."""
+def _evaluate_clip(depther, item: dict, min_depth, max_depth, depth_align, pred_depth_scale_factor, eval_max_depth, device) -> Dict[str, object]:
+    """One clip of evaluate_depth_video.py:163-215: ``infer_video_depth`` -> depth -> alignment -> per-frame errors and
+    frame-to-frame TAE (x100) / TAS."""
     MIN_DEPTH = 1e-3
-    errors: List[Tuple[float, ...]] = []
-    temporal: List[List[float]] = []
-    times: List[float] = []
-    ratios: List[float] = []
-    aligns: List[Tuple[float, float, float, float]] = []
-    for item in dataset:
-        colors, gts, poses, Ks = item["colors"], item["depths"], item["poses"], item["Ks"]
-        t0 = time.time()
-        disp = depther.infer_video_depth(colors, device=device) if device is not None else depther.infer_video_depth(colors)
-        times.append(time.time() - t0)
-        _, pred = disp_to_depth(disp, min_depth, max_depth)
-        if depth_align == "scale":
-            pred, ratio = median_scaling(gts, pred)
-            if not np.isnan(ratio).all():
-                ratios.append(float(ratio))
-        elif depth_align == "scale_shift":
-            pred, *abcd = align_shift_and_scale(gts, pred)
-            aligns.append(tuple(float(v) for v in abcd))
-        prev = None
-        for p, g, pose, K in zip(pred, gts, poses, Ks):
-            valid = (g > MIN_DEPTH) & (g < eval_max_depth)
-            p = np.clip(p * pred_depth_scale_factor, MIN_DEPTH, eval_max_depth)
-            err = compute_errors(g, p, valid)
-            if not np.isnan(err).all():
-                errors.append(err)
-            i2w = np.linalg.inv(K @ pose)
-            if prev is not None:
-                temporal.append([tae(prev[0], prev[1], prev[2], p, valid, i2w) * 100.0, tas(prev[0], prev[1], prev[2], p, valid, i2w)])
-            prev = (p, valid, i2w)
-    return {"errors": np.array(errors), "temporal": np.array(temporal), "inference_times": np.array(times), "ratios": np.array(ratios),
-            "aligns": np.array(aligns)}
+    colors, gts, poses, Ks = item["colors"], item["depths"], item["poses"], item["Ks"]
+    rec: Dict[str, object] = {"errors": [], "temporal": [], "ratio": None, "align": None}
+    t0 = time.time()
+    disp = depther.infer_video_depth(colors, device=device) if device is not None else depther.infer_video_depth(colors)
+    rec["time"] = time.time() - t0
+    _, pred = disp_to_depth(disp, min_depth, max_depth)
+    if depth_align == "scale":
+        pred, ratio = median_scaling(gts, pred)
+        if not np.isnan(ratio).all():
+            rec["ratio"] = float(ratio)
+    elif depth_align == "scale_shift":
+        pred, *abcd = align_shift_and_scale(gts, pred)
+        rec["align"] = tuple(float(v) for v in abcd)
+    prev = None
+    for p, g, pose, K in zip(pred, gts, poses, Ks):
+        valid = (g > MIN_DEPTH) & (g < eval_max_depth)
+        p = np.clip(p * pred_depth_scale_factor, MIN_DEPTH, eval_max_depth)
+        err = compute_errors(g, p, valid)
+        if not np.isnan(err).all():
+            rec["errors"].append(tuple(float(e) for e in err))
+        i2w = np.linalg.inv(K @ pose)
+        if prev is not None:
+            rec["temporal"].append([tae(prev[0], prev[1], prev[2], p, valid, i2w) * 100.0, tas(prev[0], prev[1], prev[2], p, valid, i2w)])
+        prev = (p, valid, i2w)
+    return rec
+
+
+def evaluate_video(depther, dataset: Iterable[dict], *, min_depth: float = 0.1, max_depth: float = 150.0, depth_align: str = "scale",
+                   pred_depth_scale_factor: float = 1.0, eval_max_depth: float = 150.0, device: str = "cuda",
+                   rank: Optional[int] = None, world: Optional[int] = None) -> Optional[Dict[str, object]]:
+    """The loop of evaluate_depth_video.py:163-215.  ``depther`` only needs ``infer_video_depth(colors)``.
+
+    Clips are independent units: with ``world`` > 1 (default: the ``torch.distributed`` process group, if any) rank r
+    evaluates clips r, r + world, ... on its own GPU -- indexed directly when the dataset supports ``len`` / ``[]`` (the reference's
+    SCAREDVideos does), skipped over otherwise -- and rank 0 gathers the per-clip records and concatenates them in clip order, so
+    the result equals the one-rank run's bit for bit.  The other ranks return None.  No collective on the data path."""
+    from . import parallel
+
+    if rank is None or world is None:
+        rank, world = parallel.rank_world()
+    args = (min_depth, max_depth, depth_align, pred_depth_scale_factor, eval_max_depth, device)
+    indexable = hasattr(dataset, "__getitem__") and hasattr(dataset, "__len__")
+    if indexable:
+        n_clips = len(dataset)
+        mine = [_evaluate_clip(depther, dataset[i], *args) for i in parallel.clip_shard(n_clips, rank, world)]
+    else:
+        mine, n_clips = [], 0
+        for i, item in enumerate(dataset):
+            n_clips += 1
+            if i % world == rank:
+                mine.append(_evaluate_clip(depther, item, *args))
+    if world == 1:
+        recs = mine
+    else:
+        shards = parallel.gather_to_rank0(mine)
+        if shards is None:
+            return None
+        recs = parallel.merge_shards(shards, n_clips)
+    errors = [e for r in recs for e in r["errors"]]
+    temporal = [t for r in recs for t in r["temporal"]]
+    return {"errors": np.array(errors), "temporal": np.array(temporal), "inference_times": np.array([r["time"] for r in recs]),
+            "ratios": np.array([r["ratio"] for r in recs if r["ratio"] is not None]),
+            "aligns": np.array([r["align"] for r in recs if r["align"] is not None])}
 
 
 def _mean_ci(a: np.ndarray) -> Tuple[np.ndarray, np.ndarray]:
@@ -175,15 +206,20 @@ class SyntheticVideos:
         return self.n_clips
 
     def __iter__(self):
+        for c in range(self.n_clips):
+            yield self[c]
+
+    def __getitem__(self, c: int) -> dict:
         from . import synth
 
-        for c in range(self.n_clips):
-            clip = synth.synth_clip(1, self.n_frames, self.h, self.w, seed=self.seed + c, kind="tissue")[0]  # [N,3,H,W]
-            colors = (clip.transpose(0, 2, 3, 1) * 255).astype(np.uint8)
-            depths = (20.0 + 60.0 * clip.mean(axis=1)).astype(np.float32)  # 20 .. 80 units, correlated with the image
-            K = np.eye(4, dtype=np.float64)
-            K[0, 0] = K[1, 1] = 0.9 * self.w
-            K[0, 2], K[1, 2] = self.w / 2.0, self.h / 2.0
-            poses = np.stack([np.eye(4) for _ in range(self.n_frames)])
-            poses[:, 0, 3] = 0.05 * np.arange(self.n_frames)
-            yield {"colors": colors, "depths": depths, "poses": poses, "Ks": np.stack([K] * self.n_frames), "filename": f"synthetic/clip{c}/0"}
+        if not (0 <= c < self.n_clips):
+            raise IndexError(c)
+        clip = synth.synth_clip(1, self.n_frames, self.h, self.w, seed=self.seed + c, kind="tissue")[0]  # [N,3,H,W]
+        colors = (clip.transpose(0, 2, 3, 1) * 255).astype(np.uint8)
+        depths = (20.0 + 60.0 * clip.mean(axis=1)).astype(np.float32)  # 20 .. 80 units, correlated with the image
+        K = np.eye(4, dtype=np.float64)
+        K[0, 0] = K[1, 1] = 0.9 * self.w
+        K[0, 2], K[1, 2] = self.w / 2.0, self.h / 2.0
+        poses = np.stack([np.eye(4) for _ in range(self.n_frames)])
+        poses[:, 0, 3] = 0.05 * np.arange(self.n_frames)
+        return {"colors": colors, "depths": depths, "poses": poses, "Ks": np.stack([K] * self.n_frames), "filename": f"synthetic/clip{c}/0"}

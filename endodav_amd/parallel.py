@@ -10,7 +10,8 @@ the final gather of results to rank 0 — RCCL on GPUs (backend "nccl"), gloo in
 from __future__ import annotations
 
 import os
-from typing import Any, List, Optional, Sequence
+import time
+from typing import Any, Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.distributed as dist
@@ -73,16 +74,27 @@ def merge_shards(shards: Sequence[Sequence[Any]], n_units: int) -> List[Any]:
     return out
 
 
-def allreduce_gradients(params: Sequence[torch.nn.Parameter]) -> int:
+def allreduce_gradients(params: Sequence[torch.nn.Parameter], model: Optional[torch.nn.Module] = None) -> int:
     """Data-parallel fine-tune step, one clip per rank (the reference scatters dim 0 of [batch, T, ...] over
     ``nn.DataParallel`` replicas, trainer_end_to_end_video.py:731, and sums their gradients): ONE all-reduce over a flat
     fp32 buffer of every trainable gradient -- a few MB of LoRA factors -- summed, then divided by the world size.
-    A parameter without a gradient on this rank contributes zeros.  Returns the number of floats reduced."""
+
+    With ``model`` (an ``endodav_amd.endodav`` whose backward has just run) the gradients already live in one contiguous buffer
+    that the engine wrote (``edv_grad_bind_flat``) and every ``p.grad`` is a view of it: the all-reduce and the division run on that
+    buffer in place, with no copy.  Otherwise (any module, or gradients that are not such views) the gradients are packed into a
+    fresh flat buffer and copied back; a parameter without a gradient on this rank contributes zeros.
+    Returns the number of floats reduced."""
     params = [p for p in params if p.requires_grad]
     if not params:
         return 0
     world = dist.get_world_size() if dist.is_initialized() else 1
     n = sum(p.numel() for p in params)
+    flat = model.flat_gradients(params) if (model is not None and hasattr(model, "flat_gradients")) else None
+    if flat is not None:
+        if world > 1:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat /= world
+        return n
     if world == 1:
         return n
     flat = torch.zeros(n, dtype=torch.float32, device=params[0].device)
@@ -102,3 +114,40 @@ def allreduce_gradients(params: Sequence[torch.nn.Parameter]) -> int:
             p.grad.copy_(g)
         off += p.numel()
     return n
+
+
+def timed_region(step: Callable[[int], Any], steps: int, warmup: int, device: Optional[torch.device] = None) -> Tuple[float, Any]:
+    """The measurement protocol of ``bench.py`` for any number of ranks: ``warmup`` untimed calls of ``step(i)``, then EXACTLY ``steps``
+    timed calls bracketed on both sides by a device synchronisation + barrier, and the MAX over ranks of the elapsed wall time.
+    Returns (seconds, the last step's result).  ``device`` None = a CPU run (the gloo tests): no device synchronisation."""
+    def fence() -> None:
+        if device is not None and device.type == "cuda":
+            torch.cuda.synchronize(device)
+        barrier()
+
+    out = None
+    for i in range(warmup):
+        out = step(i - warmup)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        out = step(i)
+    fence()
+    return max_over_ranks(time.perf_counter() - t0, device), out
+
+
+def rank_world() -> Tuple[int, int]:
+    """(rank, world size) of the default process group; (0, 1) without one."""
+    if dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def shard_run(n_units: int, fn: Callable[[int], Any]) -> Optional[List[Any]]:
+    """Run ``fn(unit)`` for this rank's round-robin share of ``n_units`` independent units (clips of a dataset, windows of a long
+    video) and merge every rank's results back into unit order on rank 0 (None on the other ranks).  No data-path collective:
+    the only communication is the final gather of the (picklable, host-side) results."""
+    rank, world = rank_world()
+    mine = [fn(u) for u in clip_shard(n_units, rank, world)]
+    shards = gather_to_rank0(mine)
+    return None if shards is None else merge_shards(shards, n_units)

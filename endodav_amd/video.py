@@ -3,21 +3,23 @@
 ``Resize`` size rule of ``models/endodav/util/transform.py:52-105``).
 
 Differences in *where* work happens, not in what is computed:
-  - frames are uploaded once, converted to float and (if needed) bicubically resized on the GPU
-    by ``edv_resize_bicubic`` instead of per-frame ``cv2.resize`` on the host;
+  - each window's 32 frames are uploaded as uint8 while the previous window computes, converted to float and
+    (if needed) bicubically resized on the GPU by ``edv_resize_bicubic`` instead of per-frame ``cv2.resize`` on the host;
   - each window's 32 disparity maps are resized to the native frame size on the GPU by
-    ``edv_bilinear`` and come back in ONE device→host copy instead of 32;
+    ``edv_bilinear`` and come back in ONE device→host copy instead of 32, behind the next window's forward;
+  - the windows of one video are independent given the input frames (``window_sources``) and shard over ranks;
   - the least-squares scale/shift and the cross-fade run in numpy float32 exactly as the reference's.
 
 The cv2.INTER_CUBIC pre-resize is "parity unpinned" (cv2 is absent from the build
 container and the reference has no fixture for it); the kernel implements the published algorithm
 (Keys cubic, a = -0.75, half-pixel centres, clamped borders).  When the frames already have the
-network's size the resize is the identity and the whole path is pinned by ``tests/test_video.py``.
+network's size the resize is the identity and the whole path is pinned by ``tests/test_video_gpu.py``
+(windowing, key frames, stitching: reference golden) and ``tests/test_host_cpu.py`` (the host logic alone).
 """
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Optional, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
 import torch
@@ -94,65 +96,143 @@ def stitch_windows(depths: List[np.ndarray], n_keep: int) -> np.ndarray:
     return np.stack(out[:n_keep], axis=0)
 
 
+def window_sources(n_frames: int) -> List[np.ndarray]:
+    """For every window, the index of the ORIGINAL frame each of its 32 input slots shows (endodav.py:185-199).
+
+    Slots of window k are frames s0 .. s0+31 of the padded list (padding = copies of the last frame), except that the first
+    OVERLAP slots are refilled with the KEYFRAMES slots of window k-1's *input* -- itself refilled the same way, so slot 0 of
+    window k is slot 6 of window k-1, which is slot 26 of window k-2.  Inputs never depend on outputs, so the whole chain
+    resolves to indices up front and any window can be built (and run, on any GPU) independently of the others."""
+    _, starts = window_plan(n_frames)
+    out: List[np.ndarray] = []
+    for k, s0 in enumerate(starts):
+        idx = np.minimum(np.arange(s0, s0 + INFER_LEN), n_frames - 1)
+        if k > 0:
+            idx[:OVERLAP] = out[k - 1][KEYFRAMES]
+        out.append(idx)
+    return out
+
+
+class HipWindowRunner:
+    """Runs 32-frame windows of one video through the HIP forward, pipelined over three streams:
+
+      copy-in stream   window k+1: pinned uint8 frames [32, H, W, 3] -> HBM (2.5 MB .. 126 MB; the whole video is never resident,
+                       and nothing is converted to fp32 on the host: the reference ships 4x the bytes, endodav.py:195-197)
+      compute stream   window k: uint8 -> [0, 1] fp32 NCHW, bicubic pre-resize to the network's size (edv_resize_bicubic, replaces the
+                       host's per-frame cv2.resize), edv_forward, bilinear back to the frame size (edv_bilinear)
+      copy-out stream  window k-1: the 32 maps -> pinned host memory in ONE copy (the reference: 32 synchronous .cpu() calls, :205-206)
+
+    so the PCIe transfers of the neighbouring windows hide behind the forward.  Two buffers per stage; the host blocks only
+    when it is about to reuse one."""
+
+    def __init__(self, model, frames: np.ndarray, dev: torch.device):
+        self.model, self.frames, self.dev = model, frames, dev
+        self.n, self.fh, self.fw = frames.shape[:3]
+        ih, iw = model.image_shape
+        self.tw, self.th = lower_bound_size(self.fw, self.fh, iw, ih)
+
+    def run(self, sources: Sequence[np.ndarray]) -> List[np.ndarray]:
+        lib = _lib.load()
+        dev, fh, fw, th, tw = self.dev, self.fh, self.fw, self.th, self.tw
+        if not sources:
+            return []
+        nbuf = min(2, len(sources))
+        results: List[np.ndarray] = []
+        with torch.cuda.device(dev), torch.no_grad():
+            compute = torch.cuda.current_stream(dev)
+            st = C.c_void_p(_lib.stream_ptr(dev))
+            s_in, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+            h_in = [torch.empty((INFER_LEN, fh, fw, 3), dtype=torch.uint8).pin_memory() for _ in range(nbuf)]
+            d_in = [torch.empty((INFER_LEN, fh, fw, 3), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+            h_out = [torch.empty((INFER_LEN, fh, fw), dtype=torch.float32).pin_memory() for _ in range(nbuf)]
+            d_out = [torch.empty((INFER_LEN, fh, fw), dtype=torch.float32, device=dev) for _ in range(nbuf)]
+            up_done: List[Optional[torch.cuda.Event]] = [None] * nbuf     # H2D of the slot finished (host buffer reusable, device buffer valid)
+            used: List[Optional[torch.cuda.Event]] = [None] * nbuf        # the conversion that read d_in[slot] finished (device buffer reusable)
+            out_done: List[Optional[torch.cuda.Event]] = [None] * nbuf    # D2H of the slot finished
+
+            def upload(k: int) -> None:
+                slot = k % nbuf
+                if up_done[slot] is not None:
+                    up_done[slot].synchronize()       # the host buffer is about to be rewritten
+                np.take(self.frames, sources[k], axis=0, out=h_in[slot].numpy())
+                with torch.cuda.stream(s_in):
+                    if used[slot] is not None:
+                        s_in.wait_event(used[slot])   # window k-2's conversion has read the device buffer
+                    d_in[slot].copy_(h_in[slot], non_blocking=True)
+                    up_done[slot] = torch.cuda.Event()
+                    up_done[slot].record(s_in)
+
+            def drain(slot: int) -> None:
+                if out_done[slot] is not None:
+                    out_done[slot].synchronize()
+                    results.append(h_out[slot].numpy().copy())
+                    out_done[slot] = None
+
+            upload(0)
+            for k in range(len(sources)):
+                slot = k % nbuf
+                if k + 1 < len(sources):
+                    upload(k + 1)                     # overlaps window k's forward
+                compute.wait_event(up_done[slot])
+                cur = d_in[slot].permute(0, 3, 1, 2).to(torch.float32).div_(255.0)  # [32, 3, H, W] in [0, 1]
+                used[slot] = torch.cuda.Event()
+                used[slot].record(compute)
+                if (th, tw) != (fh, fw):
+                    small = torch.empty((INFER_LEN, 3, th, tw), device=dev, dtype=torch.float32)
+                    _lib.check(lib.edv_resize_bicubic(cur.data_ptr(), small.data_ptr(), INFER_LEN * 3, fh, fw, th, tw, st), "edv_resize_bicubic")
+                    cur = small
+                disp = self.model(cur.unsqueeze(0))[("disp", 0)]  # [32, 1, ih, iw]
+                drain(slot)                           # frees d_out[slot] / h_out[slot] (window k-2's copy)
+                full = d_out[slot]
+                _lib.check(lib.edv_bilinear(disp.data_ptr(), full.data_ptr(), INFER_LEN, disp.shape[-2], disp.shape[-1], 1, fh, fw, st), "edv_bilinear")
+                ready = torch.cuda.Event()
+                ready.record(compute)
+                with torch.cuda.stream(s_out):
+                    s_out.wait_event(ready)
+                    h_out[slot].copy_(full, non_blocking=True)
+                    out_done[slot] = torch.cuda.Event()
+                    out_done[slot].record(s_out)
+            for k in range(max(len(sources) - nbuf, 0), len(sources)):  # in window order: oldest slot first
+                drain(k % nbuf)
+        return results
+
+    def resized_clip(self, source: np.ndarray) -> torch.Tensor:
+        """The network input of one window, [1, 32, 3, th, tw] on the device (what ``run`` feeds the forward): for tests."""
+        lib = _lib.load()
+        with torch.cuda.device(self.dev), torch.no_grad():
+            st = C.c_void_p(_lib.stream_ptr(self.dev))
+            cur = torch.from_numpy(np.take(self.frames, source, axis=0)).to(self.dev).permute(0, 3, 1, 2).to(torch.float32).div_(255.0)
+            if (self.th, self.tw) != (self.fh, self.fw):
+                small = torch.empty((INFER_LEN, 3, self.th, self.tw), device=self.dev, dtype=torch.float32)
+                _lib.check(lib.edv_resize_bicubic(cur.data_ptr(), small.data_ptr(), INFER_LEN * 3, self.fh, self.fw, self.th, self.tw, st), "edv_resize_bicubic")
+                cur = small
+            return cur.unsqueeze(0)
+
+
 # ---------------------------------------------------------------------------------------------
-def infer_video_depth(model, frames, input_size=518, device="cuda"):
-    lib = _lib.load()
+def infer_video_depth(model, frames, input_size=518, device="cuda", runner=None):
+    """endodav.infer_video_depth (endodav.py:162-254).  With a ``torch.distributed`` process group of more than one rank the windows
+    of this ONE video are sharded round-robin over the ranks (they depend on each other through input key frames only,
+    ``window_sources``), every rank runs its share on its own GPU, rank 0 gathers the per-window maps, stitches them in window order
+    and returns the result; the other ranks return None.  No data-path collective besides that gather.
+
+    ``runner``: anything with ``run(sources) -> [np.ndarray [32, H, W]]`` (default ``HipWindowRunner``; the gloo tests pass a stub)."""
+    from . import parallel
+
     frames = np.asarray(frames)
     if frames.ndim != 4 or frames.shape[-1] != 3:
         raise ValueError(f"expected frames [N, H, W, 3], got {frames.shape}")
-    n, fh, fw = frames.shape[:3]
-    dev = torch.device(device)
-    if dev.type != "cuda":
-        raise RuntimeError("infer_video_depth runs on MI355X only (device must be a CUDA/ROCm device)")
-    ih, iw = model.image_shape
-    tw, th = lower_bound_size(fw, fh, iw, ih)
-    total, starts = window_plan(n)
-
-    with torch.cuda.device(dev), torch.no_grad():
-        st = C.c_void_p(_lib.stream_ptr(dev))
-        vid = torch.from_numpy(np.ascontiguousarray(frames)).to(dev)
-        vid = vid.permute(0, 3, 1, 2).contiguous().to(torch.float32).div_(255.0)  # [N,3,H,W] in [0,1]
-        if (th, tw) != (fh, fw):
-            small = torch.empty((n, 3, th, tw), device=dev, dtype=torch.float32)
-            _lib.check(lib.edv_resize_bicubic(vid.data_ptr(), small.data_ptr(), n * 3, fh, fw, th, tw, st), "edv_resize_bicubic")
-            vid = small
-        index = torch.arange(total, device=dev).clamp_(max=n - 1)  # padding = copies of the last frame
-
-        # The reference copies every window to the host synchronously (endodav.py:205-206).  Here the D2H of window k runs on
-        # a copy stream into one of two pinned buffers while window k+1 is computed; the host only waits for a buffer when
-        # it is about to be reused (host-side copies must not gate the GPU).
-        windows: List[np.ndarray] = []
-        copy_stream = torch.cuda.Stream(device=dev)
-        ring = [torch.empty((INFER_LEN, fh, fw), dtype=torch.float32).pin_memory() for _ in range(min(2, len(starts)))]
-        dev_full = [torch.empty((INFER_LEN, fh, fw), device=dev, dtype=torch.float32) for _ in ring]
-        done: List[Optional[torch.cuda.Event]] = [None] * len(ring)
-
-        def drain(slot: int) -> None:
-            if done[slot] is not None:
-                done[slot].synchronize()
-                windows.append(ring[slot].numpy().copy())
-                done[slot] = None
-
-        pre = None
-        for k, s0 in enumerate(starts):
-            slot = k % len(ring)
-            drain(slot)  # also frees dev_full[slot]: its copy has completed
-            cur = vid[index[s0:s0 + INFER_LEN]].unsqueeze(0).contiguous()  # [1,32,3,th,tw]
-            if pre is not None:
-                cur[:, :OVERLAP] = pre[:, KEYFRAMES]
-            disp = model(cur)[("disp", 0)]  # [32,1,ih,iw]
-            full = dev_full[slot]
-            _lib.check(lib.edv_bilinear(disp.data_ptr(), full.data_ptr(), INFER_LEN, disp.shape[-2], disp.shape[-1], 1, fh, fw, st), "edv_bilinear")
-            ready = torch.cuda.Event()
-            ready.record(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(copy_stream):
-                copy_stream.wait_event(ready)
-                ring[slot].copy_(full, non_blocking=True)
-                done[slot] = torch.cuda.Event()
-                done[slot].record(copy_stream)
-            pre = cur
-        # windows must come out in order: drain the remaining slots oldest first
-        for k in range(len(starts) - len(ring), len(starts)):
-            if k >= 0:
-                drain(k % len(ring))
-    return stitch_windows(windows, n)
+    n = frames.shape[0]
+    if runner is None:
+        dev = torch.device(device)
+        if dev.type != "cuda":
+            raise RuntimeError("infer_video_depth runs on MI355X only (device must be a CUDA/ROCm device)")
+        runner = HipWindowRunner(model, np.ascontiguousarray(frames), dev)
+    sources = window_sources(n)
+    rank, world = parallel.rank_world()
+    mine = parallel.clip_shard(len(sources), rank, world)
+    windows = runner.run([sources[k] for k in mine])
+    shards = parallel.gather_to_rank0(windows)
+    if shards is None:
+        return None
+    return stitch_windows(parallel.merge_shards(shards, len(sources)), n)

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EDV_ABI_VERSION 5
+#define EDV_ABI_VERSION 6
 
 enum edv_lora_type { EDV_LORA_NONE = 0, EDV_LORA_LORA = 1, EDV_LORA_DVLORA = 2, EDV_LORA_SSB = 3, EDV_LORA_DASH = 4 };
 
@@ -92,7 +92,9 @@ int edv_refresh_lora(edv_ctx *ctx, void *stream);
 
 /* endodav.forward (endodav.py:150-160).  x_dev: [B,T,3,H,W] fp32 in [0,1].  disp_dev[s] receives
  * ("disp", s): VDA head [B*T,1,ih,iw], [..ih/2..], ...; conv head [B*T,1,2*ph*8*.. see
- * edv_output_shape.  Requires T <= num_frames. */
+ * edv_output_shape.  Requires T <= num_frames (motion_module.py:197) and T <= 32: the temporal-attention kernels are built for the
+ * reference's window length (INFER_LEN = num_frames default = 32, endodav.py:47,62); a longer clip is refused before any work is
+ * enqueued.  On an error the internal streams are drained before the call returns. */
 int edv_forward(edv_ctx *ctx, const float *x_dev, int32_t B, int32_t T, int32_t H, int32_t W,
                 float *const disp_dev[4], void *stream);
 /* h/w of ("disp", s) for this configuration. */
@@ -105,8 +107,10 @@ int edv_stage_copy(edv_ctx *ctx, const char *name, float *dst_dev, size_t *n, vo
 int edv_set_capture(edv_ctx *ctx, int on);
 /* Live per-kernel timing for bench.py's roofline: bracket every launch of the selected kernel classes with a
  * HIP event pair on the launch stream.  Classes: 0 dense GEMM (Linear / 1x1 conv), 1 3x3 conv, 2 spatial
- * attention, 3 temporal attention, 4 LayerNorm, 5 other.  edv_profile_read waits for the recorded events,
- * returns the number of launches and their summed duration, and clears that class. */
+ * attention, 3 temporal attention, 4 LayerNorm, 5 other, 6 (read only; recorded with 0) the dense GEMMs of the encoder blocks,
+ * 7 GroupNorm (statistics + apply), 8 bilinear resample, 9 GEGLU, 10 the final 1x1 convolution to one channel, 11 resize +
+ * normalise + im2col of the input frames.  edv_profile_read waits for the recorded events, returns the number of launches and
+ * their summed duration, and clears that class. */
 int edv_profile_enable(edv_ctx *ctx, uint32_t class_mask);
 /* Frames are independent in the encoder.  n = 0 (default): automatic -- two frame groups on internal streams while a block's
  * GEMMs are short (tokens x width <= 17 M: ViT-S up to T = 32, ViT-B up to T = 16), one otherwise; n = 1..4: that many.  With more than one group the attention of one
@@ -115,8 +119,9 @@ int edv_profile_enable(edv_ctx *ctx, uint32_t class_mask);
 int edv_set_encoder_streams(edv_ctx *ctx, int32_t n);
 int edv_profile_set_mask(edv_ctx *ctx, uint32_t class_mask); /* change the bracketed classes, keep what was recorded */
 int edv_profile_read(edv_ctx *ctx, int32_t kernel_class, int32_t *launches, double *total_ms);
-/* Algorithmic work of the launches bracketed since edv_profile_enable / the last call (class 0, linear: 2 M N K FLOP and
- * 4 (M K + N K + M N (+ M N residual)) bytes per launch; 0 for classes that do not account). */
+/* Algorithmic work of the launches bracketed since edv_profile_enable / the last call: classes 0, 1, 6 book 2 M N K FLOP and every
+ * operand once in bytes (4 (M K + N K + M N (+ M N per residual))); the bandwidth-bound classes 4, 7 .. 11 book bytes only (input
+ * tensor(s) + output tensor, once each); 0 for classes that do not account. */
 int edv_profile_work(edv_ctx *ctx, int32_t kernel_class, double *flops, double *bytes);
 /* Bytes of device memory the context currently holds (packed weights + workspace). */
 size_t edv_device_bytes(const edv_ctx *ctx);
@@ -234,13 +239,19 @@ int edv_fold_lora(const float *W_dev, const float *A_dev, const float *B_dev, co
 /* ---- fine-tune step (trainer_end_to_end_video.py:731 forward, :427-431 backward/step) ----
  * edv_set_train(ctx, 1): edv_forward keeps the activations the backward needs (per encoder block: both residual-stream
  * values, the normed MLP input, q|k|v, the attention output and its log-sum-exp, the fc1 pre-activation; per motion module
- * and fusion block: the inputs of their norms and ReLUs).  Supported: VDA head (disable_conv_head), lora_type none / lora /
- * dvlora / ssb, with or without temporal_lora; no use_clstoken / residual blocks / out_sigmoid / dash: refused with an error.
- * edv_backward(ctx, disp0, grads): disp0 = the ("disp", 0) map the forward wrote, grads[k] = dL/d("disp", k), k = 0..3
- * (all four required, contiguous fp32).  Leaves the gradient of every LoRA factor of mlp.fc1 / mlp.fc2
- * ("pretrained.blocks.<i>.mlp.fc<j>.lora_{A,B,U,V}") and, with temporal_lora, of ff.net.2 in the motion modules
- * ("head.motion_modules.<m>...ff.net.2.lora_*") -- the trainable set of endodav/layers.py:5-34 -- in context-owned
- * device memory, fetched with edv_grad(ctx, name, &ptr, &numel).  edv_prepare must run again after the optimizer step. */
+ * and fusion block: the inputs of their norms and ReLUs; per output head its intermediates).  Every constructor option trains
+ * (both output heads, lora_type none / lora / dvlora / ssb / dash in both of its phases, temporal_lora, use_clstoken, residual
+ * blocks, inv_sigmoid, out_sigmoid, pe rope) except use_bn, whose train-mode BatchNorm (batch statistics) is not built: refused.
+ * ONE set of activations per context: each training forward overwrites the previous one's and advances the context's generation
+ * counter (edv_generation, read it right after the forward).
+ * edv_backward(ctx, generation, disp0, grads): generation = the forward being differentiated (0 = do not check); a mismatch with
+ * the kept activations is an error, never a silently wrong gradient.  disp0 = the ("disp", 0) map that forward wrote,
+ * grads[k] = dL/d("disp", k), k = 0..3 (all four required, contiguous fp32).  Produces the gradients edv_set_grad_scope selects,
+ * named like the state_dict: the LoRA factors of mlp.fc1 / mlp.fc2 ("pretrained.blocks.<i>.mlp.fc<j>.lora_{A,B,U,V,index}"), with
+ * temporal_lora those of ff.net.2 in the motion modules, the output-head convolutions, the residual blocks -- the trainable sets
+ * of endodav/layers.py:5-34.  Where they land: a name listed in the caller's flat buffer (edv_grad_bind_flat) is written into its
+ * slice there; any other into context-owned memory, read with edv_grad / edv_grad_copy.
+ * After the optimizer step call edv_refresh_lora (or edv_prepare) before the next forward. */
 int edv_set_train(edv_ctx *ctx, int32_t on);
 /* Which gradients the next edv_backward has to produce.  The trainer alternates spatial and temporal tuning phases
  * (trainer_end_to_end_video.py:327-339); with encoder_factors = 0 the backward stops at the head (nothing below it is
@@ -251,7 +262,16 @@ int edv_set_train(edv_ctx *ctx, int32_t on);
  * ("pretrained.blocks.<i>.residual_.{conv1,conv2,conv3}.weight", ".norm{1,2,3}.{weight,bias}"; trainable by default in the reference,
  * block.py:146-150).  Default: both factor sets, nothing else. */
 int edv_set_grad_scope(edv_ctx *ctx, int32_t encoder_factors, int32_t temporal_factors, int32_t head_convs, int32_t residual_blocks);
-int edv_backward(edv_ctx *ctx, const float *disp0_dev, const float *const grad_disp_dev[4], void *stream);
+int edv_generation(const edv_ctx *ctx, uint64_t *generation);
+int edv_backward(edv_ctx *ctx, uint64_t generation, const float *disp0_dev, const float *const grad_disp_dev[4], void *stream);
+/* One contiguous gradient buffer owned by the caller, for the data-parallel step (the reference's nn.DataParallel reduce,
+ * trainer_end_to_end_video.py:269-271; here ONE all-reduce over this buffer, in place).  names[i] / numels[i], i < n: the trainable
+ * tensors in the caller's order.  offsets_out[0..n] receives each slice's offset in floats (slices start on 16-byte boundaries) and,
+ * at [n], the total length.  flat_dev = NULL only computes the layout; otherwise flat_dev[flat_floats] must hold that total, and
+ * from then on edv_backward writes the gradient of names[i] at flat_dev + offsets_out[i] -- the host's .grad tensors are views of
+ * it, nothing is copied per tensor.  edv_backward fails if it produced no gradient for a listed name.  n = 0 unbinds. */
+int edv_grad_bind_flat(edv_ctx *ctx, int32_t n, const char *const *names, const int64_t *numels, float *flat_dev, int64_t flat_floats,
+                       int64_t *offsets_out);
 int edv_grad(edv_ctx *ctx, const char *name, float **grad_dev, int64_t *numel);
 int edv_grad_copy(edv_ctx *ctx, const char *name, float *dst_dev, int64_t numel, void *stream); /* stream-ordered copy into caller memory */
 

@@ -9,6 +9,8 @@ from __future__ import annotations
 VITS = dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384])
 VITS_SMALL_HEAD = dict(encoder="vits", features=32, out_channels=[32, 32, 64, 64])
 VITL_SMALL_HEAD = dict(encoder="vitl", features=32, out_channels=[32, 64, 64, 64])
+VITB = dict(encoder="vitb", features=128, out_channels=[96, 192, 384, 768])      # extension, SURVEY.md section 0.5 (head widths: endodac.py:184-199)
+VITL = dict(encoder="vitl", features=256, out_channels=[256, 512, 1024, 1024])   # the reference's constructor defaults
 
 # name -> (ctor kwargs, (B, T, H, W) of the input clip, clip kind, store)
 # store: "full" keeps whole outputs; "strided" keeps every 7th pixel of disp 0 + stats.
@@ -40,7 +42,18 @@ CASES = {
     "vits_224x280_conv_t2": (dict(VITS, image_shape=(224, 280), lora_type="dvlora"), (1, 2, 256, 320), "tissue", "strided"),
     # --- BASELINE config 1: ViT-S 518x518 T=4 -------------------------------------------
     "vits_518_t4": (dict(VITS, image_shape=(518, 518), lora_type="dvlora", disable_conv_head=True), (1, 4, 518, 518), "uniform", "strided"),
+    # --- BASELINE configs 3 and 5 at full size (round 2): ViT-B 518x518 T=16 and ViT-L 518x518 T=32, and ViT-L's real widths with
+    # T=32 on a small non-square grid (every temporal-attention width of config 5: C = 1024, 1024, 256, 256).  "vitb" is not
+    # constructible through the reference's endodav (KeyError): make_golden.py composes the reference's OWN
+    # vit_base (vision_transformer.py:368-382) with its DPTHeadPyramid through the 'vits' slot of the constructor.
+    "vitb_518_t16": (dict(VITB, image_shape=(518, 518), lora_type="dvlora", disable_conv_head=True), (1, 16, 518, 518), "tissue", "strided"),
+    "vitl_518_t32": (dict(VITL, image_shape=(518, 518), lora_type="dvlora", disable_conv_head=True), (1, 32, 518, 518), "tissue", "strided"),
+    "vitl_126x182_t32": (dict(VITL, image_shape=(126, 182), lora_type="dvlora", disable_conv_head=True), (1, 32, 126, 182), "tissue", "strided"),
 }
+
+# Too large for the CPU suite's replay (minutes of oracle on 8 threads): for these the CPU test only checks the oracle-vs-reference
+# agreement recorded when the fixture was made; the GPU suite runs the oracle on vitb_518_t16 at full size on the box's 16 threads.
+CPU_REPLAY_SKIP = ("vitb_518_t16", "vitl_518_t32")
 
 DASH_WARMUP_CALLS = 100  # mylora/layers.py:542 (self.warmup)
 # cases replayed by the (CPU) oracle test on every run; the 518 case takes ~5 s

@@ -198,6 +198,66 @@ def make_metrics_kat():
     print(f"metrics_kat: errors {out['compute_errors'][:3]}, tae {out['tae']:.5f}, tas {out['tas']:.4f}; wrote {os.path.getsize(path)} B")
 
 
+def loss_inputs():
+    """Deterministic inputs of the loss known-answer test (regenerated identically by tests/test_losses_cpu.py)."""
+    from endodav_amd import synth
+
+    n, H, W = 3, 20, 28
+    frames = synth.uniform("losskat:frames", (n, 3, H, W), 0.0, 1.0).astype(np.float32)
+    # neighbouring frames of a clip are correlated: frame i = a shifted blend of frame 0 and its own noise
+    for i in range(1, n):
+        frames[i] = 0.8 * np.roll(frames[0], i, axis=2) + 0.2 * frames[i]
+    disps = {s: synth.uniform(f"losskat:disp{s}", (n, 1, H >> s, W >> s), 0.05, 0.9).astype(np.float32) for s in range(4)}
+    return n, H, W, frames, disps
+
+
+def make_loss_kat():
+    """Known answers of the reference's loss layers (utils/layers.py:11-20 disp_to_depth, :134-189 BackprojectDepth / Project3D,
+    :222-236 get_smooth_loss, :276-306 SSIM) and of their composition in the trainer (trainer_end_to_end_video.py:808-868
+    generate_images_pred, :899-911 compute_reprojection_loss, :927-951 the per-scale sum) on the deterministic inputs above, with the
+    camera and the relative poses of endodav_amd.losses.synthetic_camera standing in for the pose network's outputs."""
+    from utils import layers as L
+    from endodav_amd import losses as mine
+
+    n, H, W, frames_np, disps_np = loss_inputs()
+    frames = torch.from_numpy(frames_np)
+    disps = {s: torch.from_numpy(v) for s, v in disps_np.items()}
+    K, inv_K, Tp, Tn = mine.synthetic_camera(n, H, W, "cpu")
+    out = {}
+    ssim = L.SSIM()
+    out["ssim"] = ssim(frames, torch.roll(frames, 1, 0)).numpy()
+    out["smooth"] = np.float64(L.get_smooth_loss(disps[0], frames))
+    sd, depth = L.disp_to_depth(disps[0], 0.1, 150.0)
+    out["depth"] = depth.numpy()
+    bp, pj = L.BackprojectDepth(n, H, W), L.Project3D(n, H, W)
+    cam = bp(depth, inv_K)
+    pix, _ = pj(cam, K, Tn)
+    out["cam_points"], out["pix_coords"] = cam.detach().numpy(), pix.detach().numpy()
+
+    def reprojection(pred, target):  # trainer_end_to_end_video.py:899-911 with no_ssim False
+        l1 = torch.abs(target - pred).mean(1, True)
+        return 0.85 * ssim(pred, target).mean(1, True) + 0.15 * l1
+
+    total = 0.0
+    for s in range(4):  # trainer_end_to_end_video.py:808-868 (depth, warp) and :927-951 (loss terms kept by the build: reprojection, smoothness)
+        d = torch.nn.functional.interpolate(disps[s], [H, W], mode="bilinear", align_corners=True)
+        _, dep = L.disp_to_depth(d, 0.1, 150.0)
+        cam = bp(dep, inv_K)
+        rep = 0.0
+        for T, shift, keep in ((Tp, 1, slice(1, None)), (Tn, -1, slice(None, -1))):
+            grid, _ = pj(cam, K, T)
+            warped = torch.nn.functional.grid_sample(torch.roll(frames, shift, 0), grid, padding_mode="border", align_corners=True)
+            rep = rep + reprojection(warped[keep], frames[keep]).mean()
+            if s == 0 and shift == -1:
+                out["warped_next"] = warped.numpy()
+        mean_disp = d.mean(2, True).mean(3, True)
+        total = total + rep / 2.0 + 1e-4 * L.get_smooth_loss(d / (mean_disp + 1e-7), frames) / (2 ** s)
+    out["total"] = np.float64(total / 4)
+    path = os.path.join(HERE, "loss_kat.npz")
+    np.savez_compressed(path, **out)
+    print(f"loss_kat: ssim mean {out['ssim'].mean():.5f}, smooth {out['smooth']:.6f}, total {out['total']:.6f}; wrote {os.path.getsize(path)} B")
+
+
 def dump_state_keys(ref):
     """state_dict key -> shape listings of the reference for the drop-in check."""
     import json
@@ -226,6 +286,29 @@ def dump_state_keys(ref):
     print(f"state_keys: {len(out)} configurations; wrote {os.path.getsize(path)} B")
 
 
+def build_reference(ref, kwargs):
+    """The reference model for one case.  encoder="vitb" raises KeyError in the reference's constructor although vit_base exists
+    (SURVEY.md section 0.5): that case is built from the reference's own parts -- its vit_base (vision_transformer.py:368-382)
+    handed to the constructor through the 'vits' slot (same tapped blocks [2, 5, 8, 11], endodav.py:76-85); the head takes its
+    width from pretrained.embed_dim (endodav.py:94-97), so the module tree and the state-dict keys are what a 'vitb' entry gives."""
+    import models.backbones as backbones
+
+    kw = dict(kwargs)
+    small = backbones.vits.vit_small
+    if kw["encoder"] == "vitb":
+        kw["encoder"] = "vits"
+        backbones.vits.vit_small = backbones.vits.vit_base
+    try:
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            model = ref.endodav(**kw, pretrained_path=None).eval()
+    finally:
+        backbones.vits.vit_small = small
+    if kwargs["encoder"] == "vitb":
+        assert model.pretrained.embed_dim == 768 and len(model.pretrained.blocks) == 12
+    return model
+
+
 def main(argv):
     from endodav_amd import synth
     from oracle import endodav_oracle as orc
@@ -238,13 +321,13 @@ def main(argv):
         dump_state_keys(ref)
     if not argv or "metrics" in argv:
         make_metrics_kat()
-    names = [a for a in argv if a not in ("video", "keys", "metrics")] if argv else list(CASES)
+    if not argv or "losses" in argv:
+        make_loss_kat()
+    names = [a for a in argv if a not in ("video", "keys", "metrics", "losses")] if argv else list(CASES)
     torch.set_num_threads(8)
     for name in names:
         kwargs, (B, T, H, W), kind, store = CASES[name]
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            model = ref.endodav(**kwargs, pretrained_path=None).eval()
+        model = build_reference(ref, kwargs)
         synth.fill_module_(model)
         x = torch.from_numpy(synth.synth_clip(B, T, H, W, seed=1, kind=kind))
         dash_active = name.endswith("_dash_active")

@@ -416,3 +416,105 @@ def test_unsupported_trainable_parameters_are_refused(lib, cuda):
         model(x)
     with torch.no_grad():
         model(x)  # inference is unaffected
+
+
+# ---- round 2: one set of kept activations per context; gradients land in one flat buffer -----------------------------------------
+def test_backward_of_an_overwritten_forward_is_refused(lib, cuda):
+    """A context keeps ONE set of activations.  fwd(x1), fwd(x2), loss1.backward() used to differentiate the second clip silently (plausible
+    but wrong LoRA gradients); now the backward names its forward (edv_generation) and the engine refuses a mismatch.  The latest
+    forward's backward still works, and so does the usual one-forward-per-step loop afterwards."""
+    model, kwargs, shape, kind, _ = build_model("micro_vda_dvlora")
+    x1 = case_input("micro_vda_dvlora").to(cuda)
+    x2 = torch.flip(x1, dims=[1]).contiguous() * 0.5
+    names = set_trainable(model, FACTORS)
+    model = model.to(cuda).train()
+    out1 = model(x1)
+    out2 = model(x2)  # overwrites the activations of the first forward
+    with pytest.raises(RuntimeError, match="overwrote"):
+        sum(o.sum() for o in out1.values()).backward()
+    sum(o.sum() for o in out2.values()).backward()  # the activations in the context are this forward's
+    sd = model.state_dict(keep_vars=True)
+    g2 = {n: sd[n].grad.clone() for n in names}
+    model.zero_grad(set_to_none=True)
+    ref, _ = hip_grads(model, x2.cpu(), names, [torch.ones(s, device="cpu") for s in [tuple(o.shape) for o in out2.values()]], cuda)
+    for n in names:
+        assert torch.equal(ref[n], g2[n]), n
+    # a detached, grad-enabled forward used only as a target also overwrites: the stale graph is refused, not mis-differentiated
+    out1 = model(x1)
+    with torch.no_grad():
+        model(x2)  # inference forward in between: the kept activations are gone
+    with pytest.raises(RuntimeError, match="activations"):
+        sum(o.sum() for o in out1.values()).backward()
+
+
+def test_gradients_live_in_one_flat_buffer(lib, cuda):
+    """edv_grad_bind_flat: after loss.backward() every p.grad IS its slice of one contiguous buffer the engine wrote (no per-tensor
+    copy), the slices follow state-dict order on 16-byte boundaries, and the values equal the per-tensor gradients of the context."""
+    model, kwargs, shape, kind, _ = build_model("micro_conv_dvlora")
+    x = case_input("micro_conv_dvlora").to(cuda)
+    model = model.to(cuda).train()
+    endodav_amd.mark_only_part_as_trainable(model, warm_up=True)  # LoRA A/B + the four HeadDepth heads (weights and 1-float biases)
+    params = [p for p in model.parameters() if p.requires_grad]
+    out = model(x)
+    sum((o * o).mean() for o in out.values()).backward()
+    flat = model.flat_gradients(params)
+    assert flat is not None and flat.dim() == 1
+    fg = model._last.flat
+    sd = model.state_dict(keep_vars=True)
+    assert list(fg.names) == [n for n, p in sd.items() if p.requires_grad]
+    end = 0
+    for i, n in enumerate(fg.names):
+        p = sd[n]
+        assert fg.offsets[i] % 4 == 0 and fg.offsets[i] >= end
+        end = fg.offsets[i] + p.numel()
+        assert p.grad.data_ptr() == flat.data_ptr() + 4 * fg.offsets[i], n   # a view, adopted by autograd without a copy
+        assert torch.isfinite(p.grad).all() and p.grad.abs().max() > 0, n
+    assert end <= flat.numel() < end + 4
+    # the padding between slices is zero, so reducing the whole buffer reduces exactly the gradients
+    mask = torch.ones_like(flat, dtype=torch.bool)
+    for i, n in enumerate(fg.names):
+        mask[fg.offsets[i]:fg.offsets[i] + sd[n].numel()] = False
+    assert (flat[mask] == 0).all()
+    from endodav_amd import parallel
+
+    before = flat.clone()
+    assert parallel.allreduce_gradients(params, model=model) == sum(p.numel() for p in params)  # world 1: in place, nothing to do
+    assert torch.equal(flat, before)
+    # a parameter set that is not the buffer's: the packed fallback is taken (None here)
+    assert model.flat_gradients(params[:-1]) is None
+
+
+def test_gradient_accumulation_with_the_flat_buffer(lib, cuda):
+    """Two backward passes without zero_grad: p.grad already IS the flat slice the engine is about to overwrite.  The sums must still be
+    g1 + g2 (autograd's accumulation semantics), with set_to_none=False zeroing as well."""
+    model, kwargs, shape, kind, _ = build_model("micro_vda_dvlora")
+    x1 = case_input("micro_vda_dvlora").to(cuda)
+    x2 = (1.0 - x1).contiguous()
+    names = set_trainable(model, FACTORS)
+    model = model.to(cuda).train()
+    sd = model.state_dict(keep_vars=True)
+
+    def run(x):
+        sum((o * o).mean() for o in model(x).values()).backward()
+
+    model.zero_grad(set_to_none=True)
+    run(x1)
+    g1 = {n: sd[n].grad.clone() for n in names}
+    model.zero_grad(set_to_none=True)
+    run(x2)
+    g2 = {n: sd[n].grad.clone() for n in names}
+    model.zero_grad(set_to_none=True)
+    run(x1)
+    run(x2)  # accumulates
+    for n in names:
+        assert torch.equal(sd[n].grad, g1[n] + g2[n]), n
+    model.zero_grad(set_to_none=False)  # zeros written through the views
+    run(x2)
+    for n in names:
+        assert torch.equal(sd[n].grad, g2[n]), n
+    # one tensor's .grad replaced by a foreign tensor: autograd adds the view to it; the others keep accumulating in place
+    sd[names[0]].grad = torch.ones_like(sd[names[0]])
+    run(x1)
+    assert torch.equal(sd[names[0]].grad, 1.0 + g1[names[0]])
+    for n in names[1:]:
+        assert torch.equal(sd[n].grad, g2[n] + g1[n]), n

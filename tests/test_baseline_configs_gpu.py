@@ -1,0 +1,173 @@
+"""BASELINE.json configs 3, 4 and 5 at their own sizes on MI355X (round 2; VERDICT r01 "next round" item 1).
+
+  config 3  ViT-B, 518x518, T=16 inference      golden captured from the imported reference (its own vit_base + DPTHeadPyramid,
+                                                tests/golden/make_golden.py build_reference) AND the CPU oracle at full size
+  config 4  ViT-B fine-tune                     gradient parity against autograd through the oracle (fp64 graph) at the trainer's
+                                                256x320 -> (224, 280) geometry with T=16; at 518x518 T=16 the size-independent
+                                                properties (linearity in the upstream gradient, run-to-run bit reproducibility)
+  config 5  ViT-L, 518x518, T=32                golden captured from the imported reference at FULL size (strided samples + all-pixel
+                                                per-frame statistics), ViT-L's widths with T=32 on a small grid (golden), and the
+                                                properties that tie the T=32 run to runs pinned elsewhere: with every motion module's
+                                                proj_out zeroed (its default init, motion_module.py:57-58) frame i of the clip equals
+                                                the T=1 run of frame i; clips of a batch are independent.
+
+These shapes take code paths the smaller cases do not: the single-stream encoder (tokens x width > 17 M), the T > 16 head without the
+side stream, the pixel-per-workgroup temporal attention at T = 16 / 32 and C up to 1024, stream-K off beyond eight rounds.
+Gates: tests/test_forward_gpu.py (G1-G3), tests/test_backward_gpu.py (1e-3 of each tensor's scale against the fp64 graph)."""
+import numpy as np
+import pytest
+import torch
+
+import endodav_amd
+from endodav_amd import synth
+from oracle import endodav_oracle as orc
+from tests import helpers as H
+from tests.golden.cases import VITB, VITL
+from tests.test_backward_gpu import FACTORS, check, hip_grads, oracle_grads, set_trainable, upstream
+from tests.test_forward_gpu import ABS_REL_MAX, DEPTH_RTOL, DISP_RTOL, check_against_golden, run_hip
+
+pytestmark = pytest.mark.gpu
+
+
+def _report(tag, out, ref):
+    for s in range(4):
+        a, b = out[("disp", s)].cpu().numpy(), ref[("disp", s)].numpy()
+        assert a.shape == b.shape
+        e, ar, naive = H.rel_err(a, b), H.abs_rel(a, b), H.depth_rel_err(a, b)
+        de, excl = H.depth_gate(a, b)
+        print(f"\n[{tag}] disp{s}: scale-rel {e:.2e}, abs_rel {ar:.2e}, max depth rel {de:.2e} ({excl:.2%} of pixels under the 1% floor; "
+              f"all-pixel figure {naive:.2e})")
+        assert e <= DISP_RTOL and de <= DEPTH_RTOL and ar <= ABS_REL_MAX, (tag, s, e, de, ar)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# config 3
+def test_config3_vitb_518_t16_matches_the_reference_golden(cuda):
+    model, kwargs, x, out = run_hip("vitb_518_t16", cuda)
+    assert model.launch_count() > 0
+    check_against_golden("vitb_518_t16", out, "strided")
+
+
+def test_config3_vitb_518_t16_against_the_oracle_at_full_size(cuda):
+    """Every pixel of every scale against the CPU oracle on this box (about a minute of oracle)."""
+    model, kwargs, shape, kind, _ = H.build_model("vitb_518_t16")
+    x = H.case_input("vitb_518_t16")
+    sd = {k: v.detach() for k, v in model.state_dict().items()}
+    with torch.no_grad():
+        ref = orc.forward(sd, x, H.oracle_config(kwargs))
+    model = model.to(cuda)
+    with torch.no_grad():
+        out = model(x.to(cuda))
+    _report("config 3: vitb 518 T=16", out, ref)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# config 4
+def test_config4_vitb_gradients_at_the_trainer_geometry(lib, cuda):
+    """ViT-B, 256x320 frames -> image_shape (224, 280) (trainer_end_to_end_video.py:61), one clip of T=16 (scripts/train_video.sh: --T 16),
+    the scripts' --disable_residual_block --disable_conv_head with the dvlora default: every LoRA factor gradient against the oracle's
+    autograd in fp64 (see tests/test_backward_gpu.py::upstream for why the upstream gradient has a definite sign)."""
+    kwargs = dict(VITB, image_shape=(224, 280), lora_type="dvlora", disable_conv_head=True)
+    model = endodav_amd.endodav(**kwargs, pretrained_path=None)
+    synth.fill_module_(model)
+    names = set_trainable(model, FACTORS)
+    assert len(names) == 12 * 2 * 4
+    T = 16
+    x = torch.from_numpy(synth.synth_clip(1, T, 256, 320, seed=3, kind="tissue"))
+    model = model.to(cuda).train()
+    gouts = upstream([(T, 1, h, w) for (h, w) in model.output_shapes()])
+    ref64, out_ref = oracle_grads(model, kwargs, x, names, gouts, torch.float64)
+    hip, out = hip_grads(model, x, names, gouts, cuda)
+    for s in range(4):
+        a, b = out[("disp", s)].detach().cpu().double(), out_ref[("disp", s)].detach()
+        assert (a - b).abs().max().item() <= DISP_RTOL * b.abs().max().item()
+    worst = check(hip, ref64, tol=1e-3)
+    print(f"\n[config 4: vitb 224x280 T={T}] {len(names)} tensors, worst scale-relative gradient error vs the fp64 graph {worst:.2e}; "
+          f"activations + workspace {model.device_bytes() / 2 ** 30:.2f} GiB")
+
+
+def test_config4_vitb_518_t16_gradient_properties(lib, cuda):
+    """ViT-B 518x518 T=16 (no oracle run at this size): the backward is linear in dL/d disp -- doubling the upstream gradient doubles
+    every factor gradient bit for bit, the gradient of a sum is the sum of the gradients up to summation order -- and a repeated step
+    gives the same bits."""
+    kwargs = dict(VITB, image_shape=(518, 518), lora_type="dvlora", disable_conv_head=True)
+    model = endodav_amd.endodav(**kwargs, pretrained_path=None)
+    synth.fill_module_(model)
+    names = set_trainable(model, FACTORS)
+    T = 16
+    x = torch.from_numpy(synth.synth_clip(1, T, 518, 518, seed=6, kind="tissue"))
+    model = model.to(cuda).train()
+    shapes = [(T, 1, h, w) for (h, w) in model.output_shapes()]
+    ga, gb = upstream(shapes, seed=5), upstream(shapes, seed=9, signed=True)
+    clone = lambda d: {n: g.clone() for n, g in d.items()}
+    g1 = clone(hip_grads(model, x, names, ga, cuda)[0])
+    g1b = clone(hip_grads(model, x, names, ga, cuda)[0])
+    g2 = clone(hip_grads(model, x, names, [2.0 * g for g in ga], cuda)[0])
+    g3 = clone(hip_grads(model, x, names, gb, cuda)[0])
+    g4 = clone(hip_grads(model, x, names, [a + b for a, b in zip(ga, gb)], cuda)[0])
+    for n in names:
+        assert torch.isfinite(g1[n]).all() and g1[n].abs().max() > 0, n
+        assert torch.equal(g1b[n], g1[n]), n
+        assert torch.equal(g2[n], 2.0 * g1[n]), n
+        ref = g1[n] + g3[n]
+        assert (g4[n] - ref).abs().max().item() <= 2e-5 * max(ref.abs().max().item(), g1[n].abs().max().item()), n
+    print(f"\n[config 4: vitb 518 T={T}] training footprint (kept activations + workspaces + packed weights) {model.device_bytes() / 2 ** 30:.2f} GiB")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# config 5
+def test_config5_vitl_widths_t32_small_grid_matches_the_reference_golden(cuda):
+    """ViT-L's real widths (D = 1024, 24 blocks, features 256, temporal attention at C = 1024 / 1024 / 256 / 256) with T = 32 on a 9 x 13 grid."""
+    _, _, _, out = run_hip("vitl_126x182_t32", cuda)
+    check_against_golden("vitl_126x182_t32", out, "strided")
+
+
+def test_config5_vitl_518_t32_matches_the_reference_golden(cuda):
+    """The whole of config 5 against the reference run at full size in the build container (every 7th pixel of each scale and
+    per-frame statistics over all pixels)."""
+    model, _, _, out = run_hip("vitl_518_t32", cuda)
+    check_against_golden("vitl_518_t32", out, "strided")
+    print(f"\n[config 5: vitl 518 T=32] {model.launch_count()} launches, {model.device_bytes() / 2 ** 30:.2f} GiB")
+
+
+def test_config5_vitl_518_t32_frames_reduce_to_single_frame_runs(cuda):
+    """With proj_out of every motion module zeroed (the reference's default init: zero_module, motion_module.py:57-58) nothing crosses
+    frames, so frame i of the T=32 clip must equal the T=1 run of frame i (pinned at full size against the oracle by
+    tests/test_forward_gpu.py::test_larger_encoders_full_size_against_oracle) -- up to the summation order of kernels whose work
+    split depends on the number of frames.  And two clips of T=16 in one batch equal the clips run alone."""
+    kwargs = dict(VITL, image_shape=(518, 518), lora_type="dvlora", disable_conv_head=True)
+    model = endodav_amd.endodav(**kwargs).eval()
+    synth.fill_module_(model)
+    with torch.no_grad():
+        for mm in model.head.motion_modules:
+            for p in mm.temporal_transformer.proj_out.parameters():
+                p.zero_()
+    model = model.to(cuda)
+    x = torch.from_numpy(synth.synth_clip(1, 32, 518, 518, seed=7, kind="tissue")).to(cuda)
+    with torch.no_grad():
+        clip = {k: v.clone() for k, v in model(x).items()}
+        for i in (0, 13, 31):
+            one = model(x[:, i:i + 1])
+            for s in range(4):
+                a, b = clip[("disp", s)][i:i + 1], one[("disp", s)]
+                assert (a - b).abs().max().item() <= 5e-6 * b.abs().max().item(), (i, s)
+        both = model(x.reshape(2, 16, 3, 518, 518))
+        first = model(x[:, :16])
+    for s in range(4):  # zeroed proj_out: T=16 halves equal the T=32 clip's frames too
+        ref = first[("disp", s)]
+        assert (both[("disp", s)][:16] - ref).abs().max().item() <= 5e-6 * ref.abs().max().item(), s
+        assert (clip[("disp", s)][:16] - ref).abs().max().item() <= 5e-6 * ref.abs().max().item(), s
+
+
+def test_clips_of_a_batch_are_independent_with_live_temporal_attention(cuda):
+    """ViT-L widths, T = 32, B = 2 on the small grid, motion modules live: the batch equals the clips run alone."""
+    model, kwargs, shape, kind, _ = H.build_model("vitl_126x182_t32")
+    model = model.to(cuda)
+    x = torch.from_numpy(synth.synth_clip(2, 32, 126, 182, seed=8, kind="tissue")).to(cuda)
+    with torch.no_grad():
+        both = {k: v.clone() for k, v in model(x).items()}
+        for b in range(2):
+            one = model(x[b:b + 1])
+            for s in range(4):
+                ref = one[("disp", s)]
+                assert (both[("disp", s)][32 * b:32 * (b + 1)] - ref).abs().max().item() <= 5e-6 * ref.abs().max().item(), (b, s)

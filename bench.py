@@ -65,6 +65,8 @@ def parse():
     ap.add_argument("--train", action="store_true", help="time the fine-tune step instead (forward + photometric loss + HIP backward + gradient "
                     "all-reduce + AdamW on the LoRA factors; BASELINE.json config 4 shape with --encoder vitb --T 16); not the headline metric")
     ap.add_argument("--l1-loss", action="store_true", help="--train with the round-1 L1 stand-in instead of the photometric loss (A/B of the loss's share)")
+    ap.add_argument("--torch-loss", action="store_true", help="--train with the photometric loss as eager PyTorch ops (endodav_amd/losses.py::photometric_loss) "
+                    "instead of the fused HIP kernels (edv_photometric_loss): what the loss costs on the host framework")
     args = ap.parse_args()
     hw = [int(v) for v in str(args.image).lower().split("x")]
     args.image_hw = (hw[0], hw[0]) if len(hw) == 1 else (hw[0], hw[1])
@@ -309,6 +311,7 @@ def train_bench(args, model, x, dev, rank, world, kwargs):
     T, (SH, SW) = args.T, args.image_hw
     frames = x.flatten(0, 1)  # [B*T, 3, H, W]: the loss compares each frame with its warped neighbours at the frame size
     cams = [losses.synthetic_camera(T, frames.shape[-2], frames.shape[-1], dev) for _ in range(args.clips)]
+    cam_all = [torch.cat([c[i] for c in cams]) for i in range(4)]
     events = not args.no_kernel_events
     lin_from = args.steps - min(LIN_STEPS, args.steps)
     state = {}
@@ -317,6 +320,8 @@ def train_bench(args, model, x, dev, rank, world, kwargs):
     def loss_fn(out):
         if args.l1_loss:
             return sum((o - o.detach().mean()).abs().mean() for o in out.values())
+        if not args.torch_loss:
+            return losses.photometric_loss_hip(out, frames, *cam_all, clips=args.clips)
         total = 0.0
         for b in range(args.clips):
             sl = slice(b * T, (b + 1) * T)
@@ -369,7 +374,8 @@ def train_bench(args, model, x, dev, rank, world, kwargs):
                                   "edv_backward together"}
     if rank == 0:
         frames_n = world * args.clips * T * args.steps
-        loss_name = "L1 stand-in" if args.l1_loss else "photometric loss (0.85 SSIM + 0.15 L1 on the two warped neighbours + edge-aware smoothness, 4 scales)"
+        loss_name = "L1 stand-in" if args.l1_loss else ("photometric loss (0.85 SSIM + 0.15 L1 on the two warped neighbours + edge-aware smoothness, 4 scales; " +
+                                                        ("eager PyTorch ops)" if args.torch_loss else "fused HIP kernels, edv_photometric_loss)"))
         line = {
             "metric": f"fine-tune frames/sec ({SH}x{SW}, T={T} clip, LoRA factors trainable)", "value": round(frames_n / dt, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,

@@ -118,6 +118,9 @@ SIGNATURES = {
     "edv_patchify": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
     "edv_bicubic_pos": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _f64, _f64, C.c_void_p]),
     "edv_resize_bicubic": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
+    "edv_photometric_loss_workspace": (C.c_size_t, [_i32, _i32, _i32, _i32]),
+    "edv_photometric_loss": (C.c_int, [_fp, C.POINTER(C.c_void_p), C.POINTER(_i32), C.POINTER(_i32), _i32, _i32, _i32, _i32, _fp, _fp, _fp, _fp, _f32, _f32, _f32,
+                                       _fp, C.POINTER(C.c_void_p), _fp, C.c_size_t, C.c_void_p]),
     "edv_fold_lora": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _f32, _fp, _i32, _i32, _i32, C.c_void_p]),
 }
 

@@ -207,4 +207,14 @@ int edv_fold_lora(const float *W_dev, const float *A_dev, const float *B_dev, co
     return fold_lora(W_dev, A_dev, B_dev, U_dev, V_dev, scale, out_dev, nout, nin, r, (hipStream_t)stream);
 }
 
+size_t edv_photometric_loss_workspace(int32_t B, int32_t T, int32_t H, int32_t W) { return photometric_loss_workspace(B, T, H, W) * sizeof(float); }
+int edv_photometric_loss(const float *frames_dev, const float *const disp_dev[4], const int32_t disp_h[4], const int32_t disp_w[4], int32_t B, int32_t T, int32_t H,
+                         int32_t W, const float *K_dev, const float *invK_dev, const float *Tprev_dev, const float *Tnext_dev, float min_depth, float max_depth,
+                         float disparity_smoothness, float *loss_dev, float *const grad_disp_dev[4], float *workspace_dev, size_t workspace_bytes, void *stream) {
+    EDV_CHECK(disp_h && disp_w, "null argument");
+    const int dh[4] = {disp_h[0], disp_h[1], disp_h[2], disp_h[3]}, dw[4] = {disp_w[0], disp_w[1], disp_w[2], disp_w[3]};
+    return photometric_loss(frames_dev, disp_dev, dh, dw, B, T, H, W, K_dev, invK_dev, Tprev_dev, Tnext_dev, min_depth, max_depth, disparity_smoothness, loss_dev,
+                            grad_disp_dev, workspace_dev, workspace_bytes / sizeof(float), (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -4,6 +4,8 @@
 //   GroupNorm(32, eps 1e-6) on the motion-module input: motion_module.py:84,110
 // One wave per row; the row lives in registers (float4 per lane), mean and the centred second
 // moment are reduced with wavefront shuffles (two-pass in registers: no E[x^2]-E[x]^2 cancellation).
+#include <cstdlib>
+
 #include "ops.hpp"
 
 namespace edv {
@@ -12,51 +14,74 @@ namespace {
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 constexpr int LN_MAXV = 4;  // float4 per lane -> dim <= 1024
 
+// R rows per wave (the loads of all R rows are issued before the first reduction); NV = float4 per lane per row.
+template <int R, int NV>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float *__restrict__ x, RowMap in_map, const float *__restrict__ w,
                                                          const float *__restrict__ b, float *y, RowMap out_map, long long rows,
                                                          int dim, float eps, const float *__restrict__ pe, int rows_per_frame, int T, int act,
                                                          int accumulate) {
     const int lane = threadIdx.x & 63;
-    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float *xr = x + in_map(row) * dim;
+    const long long row0 = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * R;
+    if (row0 >= rows) return;
     const int nv = dim >> 2;
-    f32x4 v[LN_MAXV];
-    float s = 0.f;
+    f32x4 v[R][NV];
+    float s[R];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv) {
-            v[i] = *reinterpret_cast<const f32x4 *>(xr + 4 * c);
-            s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-        } else {
-            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < R; ++k) {
+        const long long row = row0 + k < rows ? row0 + k : rows - 1;  // past the end: a valid row again, never stored
+        const float *xr = x + in_map(row) * dim;
+        s[k] = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                v[k][i] = *reinterpret_cast<const f32x4 *>(xr + 4 * c);
+            } else {
+                v[k][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
     }
-    const float mean = wave_sum(s) / (float)dim;
-    float q = 0.f;
+    f32x4 g[NV], be[NV];
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
+    for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
         if (c < nv) {
-            const f32x4 d = v[i] - mean;
-            q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+            g[i] = *reinterpret_cast<const f32x4 *>(w + 4 * c);
+            be[i] = *reinterpret_cast<const f32x4 *>(b + 4 * c);
         }
     }
-    const float rstd = rsqrtf(wave_sum(q) / (float)dim + eps);
-    float *yr = y + out_map(row) * dim;
-    const float *per = pe ? pe + (long long)((row / rows_per_frame) % T) * dim : nullptr;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-        const int c = lane + 64 * i;
-        if (c < nv) {
-            const f32x4 g = *reinterpret_cast<const f32x4 *>(w + 4 * c);
-            const f32x4 be = *reinterpret_cast<const f32x4 *>(b + 4 * c);
-            f32x4 o = (v[i] - mean) * rstd * g + be;
-            if (per) o += *reinterpret_cast<const f32x4 *>(per + 4 * c);
-            if (act == ACT_GELU) o = f32x4{gelu_erf(o.x), gelu_erf(o.y), gelu_erf(o.z), gelu_erf(o.w)};
-            if (accumulate) o += *reinterpret_cast<const f32x4 *>(yr + 4 * c);
-            *reinterpret_cast<f32x4 *>(yr + 4 * c) = o;
+    for (int k = 0; k < R; ++k) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) s[k] += (v[k][i].x + v[k][i].y) + (v[k][i].z + v[k][i].w);  // zero beyond the row
+    }
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        if (row0 + k >= rows) break;
+        const long long row = row0 + k;
+        const float mean = wave_sum(s[k]) / (float)dim;
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                const f32x4 d = v[k][i] - mean;
+                q += (d.x * d.x + d.y * d.y) + (d.z * d.z + d.w * d.w);
+            }
+        }
+        const float rstd = rsqrtf(wave_sum(q) / (float)dim + eps);
+        float *yr = y + out_map(row) * dim;
+        const float *per = pe ? pe + (long long)((row / rows_per_frame) % T) * dim : nullptr;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = lane + 64 * i;
+            if (c < nv) {
+                f32x4 o = (v[k][i] - mean) * rstd * g[i] + be[i];
+                if (per) o += *reinterpret_cast<const f32x4 *>(per + 4 * c);
+                if (act == ACT_GELU) o = f32x4{gelu_erf(o.x), gelu_erf(o.y), gelu_erf(o.z), gelu_erf(o.w)};
+                if (accumulate) o += *reinterpret_cast<const f32x4 *>(yr + 4 * c);
+                *reinterpret_cast<f32x4 *>(yr + 4 * c) = o;
+            }
         }
     }
 }
@@ -197,10 +222,31 @@ int layernorm(const float *x, RowMap in_map, const float *w, const float *b, flo
     EDV_CHECK(rows > 0, "empty problem");
     EDV_CHECK(dim % 4 == 0 && dim <= 256 * LN_MAXV, "dim must be a multiple of 4 and <= 1024");
     EDV_CHECK(!pe || (rows_per_frame > 0 && T > 0), "pe needs rows_per_frame and T");
-    const long long blocks = (rows + 3) / 4;
+    // rows per wave.  Measured on [10960, 384] (ViT-S T=8; profiles/r02_notes.txt): 1 row 12.0 us, 2 rows 12.9, 4 rows 14.3 -- the kernel is
+    // bound by how many waves are in flight, not by one wave's load -> reduce -> store chain, so one row per wave stays the default
+    // (EDV_LN_ROWS=2 / 4 for A/B runs).
+    static const int forced = [] {
+        const char *e = getenv("EDV_LN_ROWS");
+        return e ? atoi(e) : 0;
+    }();
+    int R = 1;
+    if (forced == 1 || forced == 2 || forced == 4) R = forced;
+    if (dim > 512 && R > 2) R = 2;  // R x NV float4 of row data per lane
+    const long long blocks = (rows + 4 * R - 1) / (4 * R);
     EDV_CHECK(blocks < (1ll << 31), "grid");
-    hipLaunchKernelGGL(layernorm_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, in_map, w, b, y, out_map, rows, dim, eps, pe,
-                       rows_per_frame > 0 ? rows_per_frame : 1, T > 0 ? T : 1, act, accumulate ? 1 : 0);
+    const int rpf = rows_per_frame > 0 ? rows_per_frame : 1, TT = T > 0 ? T : 1, acc = accumulate ? 1 : 0;
+#define EDV_LN_LAUNCH(RR, NVV)                                                                                                                  \
+    hipLaunchKernelGGL((layernorm_kernel<RR, NVV>), dim3((unsigned)blocks), dim3(256), 0, st, x, in_map, w, b, y, out_map, rows, dim, eps, pe, rpf, TT, \
+                       act, acc)
+    if (dim <= 512) {
+        if (R == 4) EDV_LN_LAUNCH(4, 2);
+        else if (R == 2) EDV_LN_LAUNCH(2, 2);
+        else EDV_LN_LAUNCH(1, 2);
+    } else {
+        if (R == 2) EDV_LN_LAUNCH(2, 4);
+        else EDV_LN_LAUNCH(1, 4);
+    }
+#undef EDV_LN_LAUNCH
     EDV_LAUNCH_OK();
     return 0;
 }

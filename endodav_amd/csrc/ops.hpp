@@ -163,4 +163,11 @@ int conv3x3_s2_bwd(const float *dy, const float *wpacked, float *dx, int F, int 
 int dilate2(const float *dy, float *z, int F, int H, int W, int C, hipStream_t st);  // z[f,2oy,2ox] = dy[f,oy,ox], zeros elsewhere
 int pack_conv3x3_bwd(const float *w, float *out, int Cout, int Cin, hipStream_t st);  // [Co,Ci,3,3] -> [Ci][3][3][Co], taps flipped
 
+// ------------------------------------------------------------------------------------------
+// the fine-tune step's photometric loss + dL/d disp (loss.hip)
+size_t photometric_loss_workspace(int B, int T, int H, int W);  // floats
+int photometric_loss(const float *frames, const float *const disp[4], const int *dh, const int *dw, int B, int T, int H, int W, const float *K, const float *invK,
+                     const float *Tprev, const float *Tnext, float min_depth, float max_depth, float smoothness, float *loss, float *const grad[4], float *ws,
+                     size_t ws_floats, hipStream_t st);
+
 }  // namespace edv

@@ -118,3 +118,63 @@ def synthetic_camera(n: int, H: int, W: int, device, dtype=torch.float32):
     Tp = torch.linalg.inv(Tn)
     rep = lambda m: m.unsqueeze(0).repeat(n, 1, 1).contiguous()
     return rep(K), rep(torch.linalg.inv(K)), rep(Tp), rep(Tn)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The same loss through libendodav_hip (csrc/loss.hip): value and dL/d disp in one fused call -- seven launches per scale instead of
+# ~125 eager kernels.  `photometric_loss` above stays the definition the kernels are tested against (tests/test_loss_gpu.py) and the
+# path for CPU tensors.
+_WS: Dict[Tuple, torch.Tensor] = {}
+
+
+class _PhotometricLossHip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, frames, K, inv_K, T_prev, T_next, clips, smoothness, d0, d1, d2, d3):
+        import ctypes as C
+
+        from . import _lib
+
+        lib = _lib.load()
+        disps = [d.detach().contiguous().float() for d in (d0, d1, d2, d3)]
+        N, _, H, W = frames.shape
+        if N % clips:
+            raise ValueError(f"{N} frames do not split into {clips} clips")
+        T = N // clips
+        dev = frames.device
+        mats = [m.detach().contiguous().float() for m in (K, inv_K, T_prev, T_next)]
+        for m in mats:
+            if tuple(m.shape) != (N, 4, 4):
+                raise ValueError(f"camera matrices must be [{N}, 4, 4], got {tuple(m.shape)}")
+        fr = frames.detach().contiguous().float()
+        with torch.cuda.device(dev):
+            nbytes = lib.edv_photometric_loss_workspace(clips, T, H, W)
+            if nbytes == 0:
+                raise ValueError("the photometric loss needs clips of at least two frames of at least 3x3 pixels")
+            key = (str(dev), clips, T, H, W)
+            ws = _WS.get(key)
+            if ws is None or ws.numel() * 4 < nbytes:
+                ws = _WS[key] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+            loss = torch.empty((), dtype=torch.float32, device=dev)
+            grads = [torch.empty_like(d) for d in disps]
+            dptr = (C.c_void_p * 4)(*[d.data_ptr() for d in disps])
+            gptr = (C.c_void_p * 4)(*[g.data_ptr() for g in grads])
+            dh = (C.c_int32 * 4)(*[d.shape[-2] for d in disps])
+            dw = (C.c_int32 * 4)(*[d.shape[-1] for d in disps])
+            _lib.check(lib.edv_photometric_loss(fr.data_ptr(), dptr, dh, dw, clips, T, H, W, mats[0].data_ptr(), mats[1].data_ptr(), mats[2].data_ptr(),
+                                                mats[3].data_ptr(), MIN_DEPTH, MAX_DEPTH, float(smoothness), loss.data_ptr(), gptr, ws.data_ptr(), ws.numel() * 4,
+                                                C.c_void_p(_lib.stream_ptr(dev))), "edv_photometric_loss")
+        ctx.grads = grads
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        return (None,) * 7 + tuple(g * gr for gr in ctx.grads)
+
+
+def photometric_loss_hip(disps: Dict[Tuple[str, int], torch.Tensor], frames: torch.Tensor, K: torch.Tensor, inv_K: torch.Tensor, T_prev: torch.Tensor,
+                         T_next: torch.Tensor, clips: int = 1, disparity_smoothness: float = DISPARITY_SMOOTHNESS) -> torch.Tensor:
+    """``photometric_loss`` for ``clips`` clips at once (``frames`` [clips*T, 3, H, W], matrices [clips*T, 4, 4]; the mean over the clips)
+    on MI355X through ``edv_photometric_loss``.  Differentiable with respect to the four disparity maps."""
+    if not frames.is_cuda:
+        raise RuntimeError("photometric_loss_hip runs on MI355X only; use photometric_loss for CPU tensors")
+    return _PhotometricLossHip.apply(frames, K, inv_K, T_prev, T_next, int(clips), float(disparity_smoothness), *[disps[("disp", s)] for s in range(4)])

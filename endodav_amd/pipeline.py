@@ -19,35 +19,27 @@ class ClipPipeline:
     each clip as pinned host tensors (valid until the next result is taken).  ``forward`` is the model (or any callable
     mapping a device clip to a dict / sequence of device tensors); it runs on the current stream of ``device``."""
 
-    def __init__(self, forward: Callable, device: torch.device, depth: int = 2):
+    def __init__(self, forward: Callable, device: torch.device, depth: int = 2, copy_streams: int = 2):
         self.forward, self.dev, self.depth = forward, torch.device(device), max(2, int(depth))
-        self._h_in: List[Optional[torch.Tensor]] = [None] * self.depth
         self._d_in: List[Optional[torch.Tensor]] = [None] * self.depth
         self._h_out: List[Optional[List[torch.Tensor]]] = [None] * self.depth
+        # copy_streams: 2 = uploads and downloads on separate streams (default; measured 10.90 ms/clip against 10.55 resident), 1 = one
+        # shared copy stream (11.37), 0 = downloads on the compute stream itself (10.90)   (profiles/r02_pcie_pipeline.txt)
         self.s_in = torch.cuda.Stream(device=self.dev)
-        self.s_out = torch.cuda.Stream(device=self.dev)
+        self.s_out = torch.cuda.Stream(device=self.dev) if copy_streams >= 2 else (self.s_in if copy_streams == 1 else None)
 
     def _stage_in(self, slot: int, clip: torch.Tensor, up_done, used) -> None:
-        if self._h_in[slot] is None or self._h_in[slot].shape != clip.shape:
-            self._h_in[slot] = torch.empty(clip.shape, dtype=torch.float32).pin_memory()
+        if self._d_in[slot] is None or self._d_in[slot].shape != clip.shape:
             self._d_in[slot] = torch.empty(clip.shape, dtype=torch.float32, device=self.dev)
-        if up_done[slot] is not None:
-            up_done[slot].synchronize()  # the pinned buffer is about to be rewritten
-        if clip.data_ptr() != self._h_in[slot].data_ptr():
-            self._h_in[slot].copy_(clip)
+        # A pinned clip is uploaded asynchronously from where it lies.  A pageable one goes up with a blocking copy on the copy stream (the
+        # driver stages it): the host waits ~2 ms, the GPU keeps computing the previous clip.  Staging it through a pinned buffer by hand is
+        # far slower -- host writes into pinned memory run at ~2 GB/s on this platform (profiles/r02_pcie_pipeline.txt).
         with torch.cuda.stream(self.s_in):
             if used[slot] is not None:
                 self.s_in.wait_event(used[slot])  # the forward that read the device buffer has finished
-            self._d_in[slot].copy_(self._h_in[slot], non_blocking=True)
+            self._d_in[slot].copy_(clip, non_blocking=clip.is_pinned())
             up_done[slot] = torch.cuda.Event()
             up_done[slot].record(self.s_in)
-
-    def pinned_input(self, slot: int, shape: Sequence[int]) -> torch.Tensor:
-        """The pinned staging buffer of a slot: a producer that fills it directly (a decoder, a dataset worker) saves the host copy."""
-        if self._h_in[slot] is None or tuple(self._h_in[slot].shape) != tuple(shape):
-            self._h_in[slot] = torch.empty(tuple(shape), dtype=torch.float32).pin_memory()
-            self._d_in[slot] = torch.empty(tuple(shape), dtype=torch.float32, device=self.dev)
-        return self._h_in[slot]
 
     def run(self, clips) -> Iterator[List[torch.Tensor]]:
         # (a generator: no context manager may stay entered across a yield -- torch.no_grad / torch.cuda.device are thread state and
@@ -86,13 +78,16 @@ class ClipPipeline:
             with torch.cuda.device(dev), torch.no_grad():
                 if self._h_out[slot] is None or any(h.shape != m.shape for h, m in zip(self._h_out[slot], maps)):
                     self._h_out[slot] = [torch.empty(m.shape, dtype=m.dtype).pin_memory() for m in maps]
-                with torch.cuda.stream(self.s_out):
-                    self.s_out.wait_event(used[slot])
+                s_out = self.s_out if self.s_out is not None else torch.cuda.current_stream(dev)
+                with torch.cuda.stream(s_out):
+                    if self.s_out is not None:
+                        s_out.wait_event(used[slot])
                     for h, m in zip(self._h_out[slot], maps):
                         h.copy_(m, non_blocking=True)
-                        m.record_stream(self.s_out)
+                        if self.s_out is not None:
+                            m.record_stream(s_out)
                     out_done[slot] = torch.cuda.Event()
-                    out_done[slot].record(self.s_out)
+                    out_done[slot].record(s_out)
             pending.append(slot)
             k += 1
         for slot in list(pending):  # oldest first

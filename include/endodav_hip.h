@@ -275,6 +275,22 @@ int edv_grad_bind_flat(edv_ctx *ctx, int32_t n, const char *const *names, const 
 int edv_grad(edv_ctx *ctx, const char *name, float **grad_dev, int64_t *numel);
 int edv_grad_copy(edv_ctx *ctx, const char *name, float *dst_dev, int64_t numel, void *stream); /* stream-ordered copy into caller memory */
 
+/* ---- the fine-tune step's loss ----
+ * The trainer's photometric loss on the four disparity maps of B clips of T frames, and its gradient with respect to them, in one
+ * call: per scale the map is resized to the frame size (bilinear, align_corners; trainer_end_to_end_video.py:813-817), turned into
+ * depth (utils/layers.py:11-20), back-projected and projected into the previous / next frame of the clip (utils/layers.py:134-189),
+ * the neighbour is sampled there (F.grid_sample, border padding, align_corners; trainer :853-857) and compared with the frame by
+ * 0.85 SSIM + 0.15 L1 (trainer :899-911, utils/layers.py:276-306), plus disparity_smoothness / 2^s times the edge-aware smoothness
+ * of the mean-normalised map (utils/layers.py:222-236, trainer :944-946); mean over the four scales (trainer :968).  The pose
+ * network's outputs are inputs here: K, invK, Tprev, Tnext are [B*T, 4, 4] row-major (Tprev / Tnext: pose from frame i to frames
+ * i-1 / i+1; the first / last frame of a clip has no such neighbour and is left out of that term).  frames [B*T, 3, H, W] in [0, 1];
+ * disp_dev[s] [B*T, 1, disp_h[s], disp_w[s]]; loss_dev receives ONE float; grad_disp_dev[s] receives dL/d disp_dev[s] (same shape).
+ * Deterministic (gathers and fixed-order two-stage sums, no float atomics).  T >= 2, H, W >= 3. */
+size_t edv_photometric_loss_workspace(int32_t B, int32_t T, int32_t H, int32_t W); /* bytes */
+int edv_photometric_loss(const float *frames_dev, const float *const disp_dev[4], const int32_t disp_h[4], const int32_t disp_w[4], int32_t B, int32_t T, int32_t H,
+                         int32_t W, const float *K_dev, const float *invK_dev, const float *Tprev_dev, const float *Tnext_dev, float min_depth, float max_depth,
+                         float disparity_smoothness, float *loss_dev, float *const grad_disp_dev[4], float *workspace_dev, size_t workspace_bytes, void *stream);
+
 /* ---- backward kernels (input gradients of the frozen operators, gradients of the LoRA factors): input gradients of the frozen operators and the gradients of the
  * LoRA factors, the only trainable tensors (endodav/layers.py:5-34).  Same layouts as the forward kernels. ---- */
 /* LayerNorm (no affine gradient): dx (+)= dLN(x; w, eps)(dy);  rows x dim, dim % 4 == 0, dim <= 1024. */

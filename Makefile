@@ -6,7 +6,7 @@ OUT      := endodav_amd/lib/libendodav_hip.so
 SRCS     := $(CSRC)/gemm.hip $(CSRC)/gemm_sb.hip $(CSRC)/gemm_dma.hip $(CSRC)/conv_dma.hip $(CSRC)/attn_spatial.hip $(CSRC)/attn_spatial_bwd.hip $(CSRC)/norms.hip $(CSRC)/temporal.hip \
             $(CSRC)/resample.hip $(CSRC)/prep.hip $(CSRC)/bwd.hip $(CSRC)/wgrad.hip $(CSRC)/loss.hip $(CSRC)/engine.hip $(CSRC)/api.hip
 OBJS     := $(SRCS:$(CSRC)/%.hip=build/%.o)
-HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -fno-gpu-rdc
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++20 -fPIC -Wall -Wno-unused-function -fno-gpu-rdc
 
 all: $(OUT)
 

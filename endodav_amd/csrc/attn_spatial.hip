@@ -24,7 +24,10 @@
 // task leaves (unnormalised Oᵀ, running max, running sum) in a workspace slot — at most two per workgroup — and
 // attn_combine_kernel merges the pieces of each leftover task (the usual log-sum-exp merge, in base 2).
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 
 #include "ops.hpp"
 
@@ -237,6 +240,235 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_kernel(const float *__re
     }
 }
 
+// ---- the VALU-lean form (round 2) ------------------------------------------------------------------------------------------------
+// Same task list, piece format and result (to fp32 rounding) as attn_spatial_kernel<4, 64>.  What the round-2 measurements said
+// (profiles/r02_notes.txt, scratch/ubench/mfma_feed.hip): the chip holds 2.34 GHz under this kernel, LDS has no conflicts, yet the matrix
+// pipe is busy 79 % of the cycles -- because on this part the f32 MFMA and the VALU do not overlap (the f32 MFMA runs at exactly the f32
+// vector rate): every VALU instruction between MFMAs costs its 4-8 issue cycles of matrix time, for both waves of the SIMD, whether it
+// is interleaved with the MFMAs or not (a version that hid the softmax of tile t behind the PV MFMAs of tile t-1 measured 3 % SLOWER).
+// The round-1 loop issued ~365 VALU instructions per 128 MFMAs: 127 accumulator-file moves (the compiler parked O in AGPRs), 62 compare /
+// select pairs of the sequence-end mask on EVERY tile (if-converted), 33 subtractions of the running max, 32 address adds, ~32 rescale
+// multiplies.  This kernel issues ~115:
+//   * all registers in the unified VGPR file (__launch_bounds__(256, 2)): no v_accvgpr moves;
+//   * the score accumulators start at -m (the running reference, one value per lane = per query) instead of 0, so the MFMA delivers s - m
+//     and exp2 applies to the accumulator as it stands;
+//   * the reference moves only when a tile's largest score exceeds it by more than 2^10 (or on a run's first tile): then, and only
+//     then, the 32 scores, O and l are rebased.  exp2(s - m) stays <= 2^10: same result to rounding, the usual flash-attention freedom;
+//   * the sequence-end mask is a real branch (last tile only);
+//   * K/V tiles arrive by LDS-DMA through buffer descriptors: per-lane byte offsets are kernel constants, the tile / head / K-or-V
+//     advance sits in the SCALAR offset, rows past the sequence end fall outside the descriptor and read as zeros; two LDS stages per
+//     operand and a loop unrolled by two make every fragment address a register + immediate: no address arithmetic in the loop, one
+//     barrier per tile.  K rows are XOR-swizzled 256-byte lines (b128 reads down a column), V rows are linear (b32 reads along a row).
+// (not a template: hipcc 7.2 silently fails to instantiate the host stub of a kernel TEMPLATE whose body holds this generic lambda)
+constexpr int LEAN_NW = 4;
+__global__ __launch_bounds__(LEAN_NW * 64, 2) void attn_lean_kernel(const float *__restrict__ qkv, float *__restrict__ out, float *__restrict__ ws,
+                                                               float *__restrict__ lse, int N, int heads, int whole_rounds, long long units, int chunk) {
+    constexpr int NW = LEAN_NW, KT = 64, QB = NW * 32;
+    constexpr int SLOTF = QB * (HD + 2);
+    constexpr int TILE = KT * HD;  // floats per staged tile (16 KB)
+    constexpr int RPW = KT / NW;   // tile rows each wave stages (16), 4 rows per DMA instruction
+    constexpr float TAU = 10.0f;   // rebase the softmax reference when a score exceeds it by more than 2^TAU
+    __shared__ __attribute__((aligned(16))) float smem[4 * TILE];  // K stage 0, K stage 1, V stage 0, V stage 1
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int nq = (N + QB - 1) / QB;
+    const int G = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = G >> 3, r = G & 7, x = bid & 7, loc = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+    }
+    const int D = heads * HD, D3 = 3 * D;
+    const int ntiles = (N + KT - 1) / KT;
+    const float qscale = 0.125f * 1.44269504088896340736f;
+    // DMA: instruction i of this wave fills tile rows RPW*wave + 4i .. + 3; this lane's 16 bytes: row drow of those, chunk position dpos
+    const int drow = lane >> 4, dpos = lane & 15;
+    unsigned vk[RPW / 4], vv[RPW / 4];  // byte offsets inside a (frame, tile 0, head 0, column block 0) window
+#pragma unroll
+    for (int i = 0; i < RPW / 4; ++i) {
+        const int r = RPW * wave + 4 * i + drow;
+        vk[i] = (unsigned)(r * D3 + ((dpos ^ (r & 15)) << 2)) * 4u;
+        vv[i] = (unsigned)(r * D3 + (dpos << 2)) * 4u;
+    }
+    // fragment addresses in stage 0: K chunk 2qq + lh of row l31 (and of row 32 + l31: + 8 KB); V row 4 lh, float l31
+    const float *kaddr[8];
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq) kaddr[qq] = smem + l31 * HD + (((2 * qq + lh) ^ (l31 & 15)) << 2);
+    const float *vaddr = smem + 2 * TILE + 4 * lh * HD + l31;
+    // Rows past the sequence end are not written by the DMA (outside the descriptor): whatever the stage held before stays.  Their scores
+    // are masked and their probabilities are exactly 0, but 0 x NaN is NaN in the PV product -- so the stages start as zeros, not as
+    // whatever bit patterns the LDS held.
+    for (int i = tid; i < 4 * TILE; i += NW * 64) smem[i] = 0.f;
+    __syncthreads();
+
+    const int task_l0 = whole_rounds * G;
+    long long u = (long long)bid * chunk;
+    const long long u_end = u + chunk < units ? u + chunk : units;
+    int round = 0, seg = 0;
+    for (;;) {
+        int task, kt0, kt1;
+        float *part = nullptr;
+        if (round < whole_rounds) {
+            task = round * G + bid;
+            kt0 = 0;
+            kt1 = ntiles;
+            ++round;
+        } else if (u < u_end) {
+            const int t = (int)(u / ntiles);
+            kt0 = (int)(u - (long long)t * ntiles);
+            const long long left = u_end - u;
+            kt1 = kt0 + left < ntiles ? kt0 + (int)left : ntiles;
+            task = task_l0 + t;
+            u += kt1 - kt0;
+            if (!(kt0 == 0 && kt1 == ntiles)) part = ws + ((long long)bid * 2 + seg) * SLOTF;
+            ++seg;
+        } else {
+            break;
+        }
+        const int qt = task % nq, fh = task / nq;
+        const int head = fh % heads, frame = fh / heads;
+        const float *fbase = qkv + (long long)frame * N * D3;  // this frame's q|k|v rows
+        const float *base = fbase + head * HD;
+        const int qi = qt * QB + wave * 32 + l31;
+        const int qrow = qi < N ? qi : N - 1;
+        // descriptor over the frame's N rows: a key row >= N lies beyond num_records and reads as zeros (masked below anyway)
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(fbase), 0, (unsigned)N * (unsigned)D3 * 4u, 0x00020000);
+
+        f32x4 qf[8];
+#pragma unroll
+        for (int qq = 0; qq < 8; ++qq) {
+            f32x4 v = *reinterpret_cast<const f32x4 *>(base + (long long)qrow * D3 + 8 * qq + 4 * lh);
+            qf[qq] = v * qscale;
+        }
+        // which = 1: K (column block D), 2: V (column block 2 D) of key tile t into stage st
+        auto issue = [&](int t, int st, int which) {
+            float *dst = smem + (which == 1 ? 0 : 2 * TILE) + st * TILE + (RPW * wave_s) * HD;
+            const int soff = ((t * KT) * D3 + which * D + head * HD) * 4;
+#pragma unroll
+            for (int i = 0; i < RPW / 4; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(dst + 4 * i * HD), 16, which == 1 ? vk[i] : vv[i], soff, 0, 0);
+        };
+        f32x16 o0, o1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+        float m_run = 0.f, l_run = 0.f;  // m_run: the reference the scores are taken against (set by the run's first tile)
+
+        // one key tile out of stage ST; FIRST = the run's first tile (no reference yet)
+        auto tile = [&](int t, auto st_tag, auto first_tag) {
+            constexpr int ST = decltype(st_tag)::value;
+            constexpr bool FIRST = decltype(first_tag)::value;
+            const int k0 = t * KT;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of K(t) and V(t) has landed
+            __builtin_amdgcn_s_barrier();                      // ... everybody's has; and every wave is done with the other stage
+            if (t + 1 < kt1) {
+                issue(t + 1, ST ^ 1, 1);
+                issue(t + 1, ST ^ 1, 2);
+            }
+            // ---- S^T - m = K Q^T - m: the accumulators start at minus the reference
+            f32x16 s0, s1;
+            const float init = FIRST ? 0.f : -m_run;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s0[r] = s1[r] = init;
+#pragma unroll
+            for (int qq = 0; qq < 8; ++qq) {
+                const f32x4 ka = *reinterpret_cast<const f32x4 *>(kaddr[qq] + ST * TILE);
+                const f32x4 kb = *reinterpret_cast<const f32x4 *>(kaddr[qq] + ST * TILE + 32 * HD);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s0 = __builtin_amdgcn_mfma_f32_32x32x2f32(ka[e], qf[qq][e], s0, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f32_32x32x2f32(kb[e], qf[qq][e], s1, 0, 0, 0);
+                }
+            }
+            if (k0 + KT > N) {  // the sequence's last, partial tile only (the empty asm keeps this a real branch)
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (k0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= N) s0[r] = -INFINITY;
+                    if (k0 + 32 + (r & 3) + 8 * (r >> 2) + 4 * lh >= N) s1[r] = -INFINITY;
+                }
+            }
+            float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            // rebase?  (wave-uniform decision; each lane then moves by its own amount)
+            if (FIRST || __builtin_amdgcn_ballot_w64(mx > TAU) != 0) {
+                const float d = FIRST ? mx : fmaxf(mx, 0.f);
+                const float alpha = FIRST ? 0.f : __builtin_amdgcn_exp2f(-d);
+                m_run += d;
+                l_run *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s0[r] -= d;
+                    s1[r] -= d;
+                    o0[r] *= alpha;
+                    o1[r] *= alpha;
+                }
+            }
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s0[r] = __builtin_amdgcn_exp2f(s0[r]);
+                psum += s0[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s1[r] = __builtin_amdgcn_exp2f(s1[r]);
+                psum += s1[r];
+            }
+            l_run += psum;
+            // ---- O^T += V^T P^T: register r of lane-half h of sub-tile u is key 32 u + (r&3) + 8 (r>>2) + 4 h
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float *va = vaddr + ST * TILE + ((r & 3) + 8 * (r >> 2)) * HD;
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[0], s0[r], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32], s0[r], o1, 0, 0, 0);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32 * HD], s1[r], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(va[32 * HD + 32], s1[r], o1, 0, 0, 0);
+            }
+        };
+        issue(kt0, 0, 1);
+        issue(kt0, 0, 2);
+        tile(kt0, std::integral_constant<int, 0>{}, std::true_type{});
+        {
+            int t = kt0 + 1;
+            for (; t + 1 < kt1; t += 2) {
+                tile(t, std::integral_constant<int, 1>{}, std::false_type{});
+                tile(t + 1, std::integral_constant<int, 0>{}, std::false_type{});
+            }
+            if (t < kt1) tile(t, std::integral_constant<int, 1>{}, std::false_type{});
+        }
+        __builtin_amdgcn_s_barrier();  // every wave has read its last V tile before the next run's first DMA refills stage 0
+
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        float inv = 1.0f / l_tot;
+        float *orow = nullptr;
+        if (part) {
+            const int ql = wave * 32 + l31;
+            orow = part + ql * HD;
+            inv = 1.0f;
+            if (lh == 0) {
+                part[QB * HD + ql] = m_run;
+                part[QB * HD + QB + ql] = l_tot;
+            }
+        } else if (qi < N) {
+            orow = out + ((long long)frame * N + qi) * D + head * HD;
+            if (lse && lh == 0) lse[((long long)frame * heads + head) * N + qi] = m_run + log2f(l_tot);
+        }
+        if (orow) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 a = {o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
+                f32x4 b = {o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
+                *reinterpret_cast<f32x4 *>(orow + 8 * g + 4 * lh) = a;
+                *reinterpret_cast<f32x4 *>(orow + 32 + 8 * g + 4 * lh) = b;
+            }
+        }
+    }
+}
+
 // Merge of the pieces of every split (leftover) task.  Piece list of leftover task t: the workgroups whose unit runs
 // [g*chunk, (g+1)*chunk) intersect [t*ntiles, (t+1)*ntiles); a workgroup's piece sits in its slot 0 when its first unit
 // lies in this task, else in slot 1.  Thread = (query, 16-byte output chunk); 16 queries per 256-thread block.
@@ -290,9 +522,29 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restri
 
 struct AttnPlan {
     int nw, kt, grid, whole_rounds, chunk, ntasks, ntiles, leftover;
+    bool pipe;
     long long units;
     size_t ws_floats;
 };
+
+int pipe_slots() {
+    static const int slots = [] {
+        int dev = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, attn_lean_kernel, 256, 0) != hipSuccess) return 0;
+        if (getenv("EDV_DEBUG_SLOTS")) fprintf(stderr, "attn_lean_kernel: %d CUs x %d resident workgroups\n", cus, per_cu);
+        return cus * per_cu;
+    }();
+    return slots;
+}
+bool use_pipe() {
+    static const bool on = [] {
+        const char *e = getenv("EDV_ATTN_LEAN");  // 0: the round-1 kernel (register-staged K/V, ~365 VALU instructions per key tile), for A/B runs
+        return !(e && atoi(e) == 0);
+    }();
+    return on;
+}
 
 template <int NW, int KT>
 int resident_slots() {
@@ -326,7 +578,9 @@ int make_plan(int F, int N, int heads, AttnPlan *p) {
     if (forced == 1 || forced == 2 || forced == 4) nw = forced;
     p->nw = nw;
     p->kt = nw == 4 ? (kt_forced == 32 ? 32 : 64) : 32;  // 32-key tiles measured equal at N = 1370 (283.7 vs 284.0 us)
-    const int slots = nw == 4 ? (p->kt == 64 ? resident_slots<4, 64>() : resident_slots<4, 32>()) : nw == 2 ? resident_slots<2, 32>() : resident_slots<1, 32>();
+    p->pipe = nw == 4 && p->kt == 64 && use_pipe();
+    const int slots = p->pipe ? pipe_slots()
+                              : nw == 4 ? (p->kt == 64 ? resident_slots<4, 64>() : resident_slots<4, 32>()) : nw == 2 ? resident_slots<2, 32>() : resident_slots<1, 32>();
     EDV_CHECK(slots > 0, "occupancy query failed");
     const long long ntasks = (long long)F * heads * ((N + nw * 32 - 1) / (nw * 32));
     EDV_CHECK(ntasks < (1ll << 31), "grid limits");
@@ -362,7 +616,9 @@ int attn_spatial(const float *qkv, float *out, int F, int N, int heads, float *w
     EDV_TRY(make_plan(F, N, heads, &p));
     EDV_CHECK(p.ws_floats == 0 || (ws && ws_floats >= p.ws_floats && (uintptr_t)ws % 16 == 0), "attention workspace too small (attn_spatial_workspace)");
     dim3 grid((unsigned)p.grid);
-    if (p.nw == 4 && p.kt == 32)
+    if (p.pipe)
+        hipLaunchKernelGGL((attn_lean_kernel), grid, dim3(256), 0, st, qkv, out, ws, lse, N, heads, p.whole_rounds, p.units, p.chunk);
+    else if (p.nw == 4 && p.kt == 32)
         hipLaunchKernelGGL((attn_spatial_kernel<4, 32>), grid, dim3(256), 0, st, qkv, out, ws, lse, N, heads, p.whole_rounds, p.units, p.chunk);
     else if (p.nw == 4)
         hipLaunchKernelGGL((attn_spatial_kernel<4, 64>), grid, dim3(256), 0, st, qkv, out, ws, lse, N, heads, p.whole_rounds, p.units, p.chunk);

@@ -973,14 +973,14 @@ struct Run {
         // Frames are independent in the encoder: with two internal streams the two halves of the batch run as
         // concurrent kernels, so workgroups of different kernels (one half's attention, the other's GEMM) co-reside
         // on the CUs and fill each other's stalls and grid tails.  The head needs all T frames again (temporal attention).
-        // Automatic: two frame groups while a block's GEMMs are short (tokens x width <= 17 M: ViT-S up to T=32, ViT-B up to T=16) -- one group's
-        // attention then runs beside the other group's GEMMs and fills their launch ramps and drains.  Measured, 2 vs 1 streams:
-        // ViT-S T=4 +2.7 %, T=8 +4.8 %, T=16 +2.4 %, T=32 +1.3 %; ViT-B T=16 +-0; ViT-L T=32 -1.3 % (profiles/r01_gemm_tile_sweep.txt).
+        // Automatic = ONE stream since round 2.  Round 1 ran two frame groups on two streams while a block's GEMMs were short, so that one
+        // group's attention filled the launch ramps and drains of the other's GEMMs (+4.8 % at T=8).  With the VALU-free GEMM loop and
+        // the VALU-lean attention kernel of round 2 the two-stream form measures equal or slower (ViT-S T=8: 772.7 vs 792.3 frames/s, ViT-B
+        // T=16: 280.9 vs 284.9; profiles/r02_notes.txt): co-resident kernels share a SIMD's matrix / vector ALUs, so one kernel's VALU
+        // work comes out of the other's matrix time, and the attention kernel's 64 KB of LDS per workgroup leaves room for one GEMM
+        // workgroup beside two of its own.  EDV_ENC_STREAMS=2..4 / edv_set_encoder_streams still select the forked form.
         int want = c->enc_streams;
-        if (want <= 0) want = (MT * (long long)D <= 17000000ll) ? 2 : 1;
-        // Not while training: the kept activations are laid out per frame (trainbuf), so two groups work, but they measure slower
-        // there (ViT-S T=8 243 vs 257 frames/s, ViT-B T=16 224^2 506 vs 539, ssb T=16 907 vs 1040: the training forward's extra
-        // stores and unfused GELU leave less idle issue time to fill).
+        if (want <= 0) want = 1;
         int nstreams = (want > 1 && !c->capture && !c->train) ? (want > 4 ? 4 : want) : 1;
         enc_F = F;
         if (nstreams > F) nstreams = F;

@@ -17,6 +17,8 @@
 // T=32 qkv 363 -> 340 us (114 TF/s); end to end +2..3 % on ViT-S/B/L.  On bare 8192x8192x1024 the DMA fill rate per CU
 // caps it near 100 TF/s (register staging: 117), a regime the model does not reach with its K <= 4096, N <= 4096.
 #include <cstdio>
+#include <cstdlib>
+#include <type_traits>
 
 #include "gemm_common.hpp"
 
@@ -51,10 +53,22 @@ constexpr int MAX_COUNTERS = SPLIT_MAX_COUNTERS;
 // SPLIT = false is the plain grid (one whole tile per workgroup): the split bookkeeping and the merge compile away, which
 // keeps the hot instantiation at 48 VGPRs and its code in the instruction cache (with the merge inlined the same launches ran
 // 2 % slower end to end).
-template <int STORE, int EP, bool SPLIT>
+//
+// The k loop carries NO vector-ALU instruction (round 2).  On this part the f32 MFMA and the VALU do not overlap: v_mfma_f32_32x32x2_f32 runs at
+// exactly the f32 vector rate, and every VALU instruction a wave issues between its MFMAs takes its 4-8 cycles out of the matrix pipe's time, for
+// all waves of the SIMD (scratch/ubench/mfma_feed.hip: 160 VALU instructions per 128 MFMAs cost 19 % whether issued as a burst or interleaved;
+// LDS reads, barriers and accumulator-to-operand forwarding cost nothing).  The round-1 loop spent ~23 VALU instructions per 16 MFMAs on
+// addresses: 64-bit adds for the four DMA sources, a v_readfirstlane per DMA for M0 (the wave index is "divergent" to the compiler), an add
+// per fragment read for the stage toggle.  Now: the DMA goes through buffer descriptors (per-lane 32-bit byte offset computed once per tile, the
+// k advance in the SCALAR offset), the wave index is made scalar once, and the loop is unrolled by two so that the LDS stage is a
+// compile-time immediate of ds_read_b128.  BUF = false keeps the flat-address form for operands beyond 4 GB.
+template <int STORE, int EP, bool SPLIT, bool BUF>
 __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g, const GemmSplit sp) {
     __shared__ __attribute__((aligned(16))) float smem[2 * DSTAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);  // the same number, provably wave-uniform: M0 and LDS bases become scalar arithmetic
+    const auto rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.A), 0, 0xffffffff, 0x00020000);
+    const auto rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.W), 0, 0xffffffff, 0x00020000);
     EDV_GEMM_STAMP(0);
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (g.N + DBN - 1) / DBN;
@@ -100,6 +114,7 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g, const G
 
         // staging: wave w owns rows [16w, 16w+16) of the A tile and of the W tile; one DMA instruction = 8 rows x 128 B
         const float *ga[2], *gb[2];
+        unsigned va[2], vb[2];  // BUF: byte offsets of this lane's 16 bytes in k-tile 0
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int r = 16 * wave + 8 * i + srow;   // row within the tile
@@ -110,17 +125,33 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g, const G
             n = n < g.N ? n : g.N - 1;
             ga[i] = g.A + g.a_map(m) * g.lda + c * 4;
             gb[i] = g.W + (long long)n * g.ldw + c * 4;
+            va[i] = (unsigned)((g.a_map(m) * g.lda + c * 4) * 4);
+            vb[i] = (unsigned)(((long long)n * g.ldw + c * 4) * 4);
         }
         auto issue = [&](int kt, int st) {
             float *sA = smem + st * DSTAGE, *sB = sA + DBM * DBK;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ga[i] + kt * DBK),
-                                                 (__attribute__((address_space(3))) void *)(sA + (16 * wave + 8 * i) * DBK), 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gb[i] + kt * DBK),
-                                                 (__attribute__((address_space(3))) void *)(sB + (16 * wave + 8 * i) * DBK), 16, 0, 0);
+                if constexpr (BUF) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void *)(sA + (16 * wave_s + 8 * i) * DBK), 16, va[i],
+                                                             kt * (DBK * 4), 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void *)(sB + (16 * wave_s + 8 * i) * DBK), 16, vb[i],
+                                                             kt * (DBK * 4), 0, 0);
+                } else {
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ga[i] + kt * DBK),
+                                                     (__attribute__((address_space(3))) void *)(sA + (16 * wave + 8 * i) * DBK), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gb[i] + kt * DBK),
+                                                     (__attribute__((address_space(3))) void *)(sB + (16 * wave + 8 * i) * DBK), 16, 0, 0);
+                }
             }
         };
+        // fragment read addresses in stage 0 (the stage toggle is an immediate offset): logical chunk 2q + lh of rows ra / rb
+        const float *pa[4], *pb[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            pa[q] = smem + ra * DBK + (((2 * q + lh) ^ swa) << 2);
+            pb[q] = smem + DBM * DBK + rb * DBK + (((2 * q + lh) ^ swb) << 2);
+        }
 
         EpiCols<1> cols;
         if (EP != 0) cols = gemm_epilogue_prefetch<1>(g, n0, wn * 32, l31);
@@ -134,22 +165,38 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g, const G
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         EDV_GEMM_STAMP(2);
-        for (int kt = kt0; kt < kt1; ++kt) {
-            const int st = (kt - kt0) & 1;
-            if (kt + 1 < kt1) issue(kt + 1, st ^ 1);  // the other stage was last read in the previous iteration (barrier passed)
-            const float *sA = smem + st * DSTAGE, *sB = sA + DBM * DBK;
+        // one k-tile out of stage ST (compile-time): DMA of the next tile into the other stage, all eight fragment reads, sixteen MFMAs
+        auto ktile = [&](int kt, auto st_tag) {
+            constexpr int ST = decltype(st_tag)::value;
+            if (kt + 1 < kt1) issue(kt + 1, ST ^ 1);  // the other stage was last read in the previous k-tile (barrier passed)
+            f32x4 fa[4], fb[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int cq = 2 * q + lh;  // logical 16-byte chunk: k = 8q + 4h .. 8q + 4h + 3 (the permuted-k trick of gemm.hip)
-                const f32x4 fa = *reinterpret_cast<const f32x4 *>(&sA[ra * DBK + ((cq ^ swa) << 2)]);
-                const f32x4 fb = *reinterpret_cast<const f32x4 *>(&sB[rb * DBK + ((cq ^ swb) << 2)]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc[0][0], 0, 0, 0);
+            for (int q = 0; q < 4; ++q) {  // k = 8q + 4h .. 8q + 4h + 3 (the permuted-k trick of gemm.hip)
+                fa[q] = *reinterpret_cast<const f32x4 *>(pa[q] + ST * DSTAGE);
+                fb[q] = *reinterpret_cast<const f32x4 *>(pb[q] + ST * DSTAGE);
             }
-            // this wave's DMAs of tile kt+1 have landed, its fragment reads of tile kt are done -> publish / release
+            // all eight reads are in flight before the first MFMA waits for its pair (left alone the scheduler sinks each pair of reads
+            // to its four MFMAs and re-uses one register quad: an LDS round trip exposed four times per k-tile)
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][e], fb[q][e], acc[0][0], 0, 0, 0);
+            // this wave's DMAs of tile kt+1 have landed, its fragment reads of tile kt are done -> publish / release.  (The fence keeps the
+            // MFMAs above the wait: they touch registers only, and the scheduler otherwise sinks fifteen of them below the barrier -- the
+            // wave then waits for its DMA one MFMA after issuing it instead of sixteen.)
+            __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+        };
+        {
+            int kt = kt0;
+            for (; kt + 1 < kt1; kt += 2) {
+                ktile(kt, std::integral_constant<int, 0>{});
+                ktile(kt + 1, std::integral_constant<int, 1>{});
+            }
+            if (kt < kt1) ktile(kt, std::integral_constant<int, 0>{});
         }
         EDV_GEMM_STAMP(3);
         if (SPLIT && part) {
@@ -208,13 +255,19 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g, const G
     }
 }
 
+// operands the 32-bit buffer offsets reach (byte offset of the last element the loop may touch, rows clamped to the edge)
+inline bool fits_buffer(const GemmDesc &d) {
+    const long long a_rows = d.a_map(d.M - 1) + 1, lim = (1ll << 32) - (1 << 20);
+    return a_rows * d.lda * 4 < lim && (long long)d.N * d.ldw * 4 < lim;
+}
+
 template <int STORE, int EP>
 int dma_slots() {
     static const int slots = [] {
         int dev = 0, cus = 0, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess) return 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_dma_kernel<STORE, EP, true>, 256, 0) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_dma_kernel<STORE, EP, true, true>, 256, 0) != hipSuccess) return 0;
         // The occupancy API answers 5 (5 x 32 KB = the whole 160 KB of LDS), the hardware places 4: the timeline of
         // scratch/ubench/gemm_trace.hip shows exactly 4 x 256 workgroups alive.  A persistent grid must match what is really
         // resident, or the surplus workgroups start only when others finish.  EDV_GEMM_SLOTS_PER_CU overrides.
@@ -232,6 +285,11 @@ int launch_dma(const GemmDesc &d, long long tiles, hipStream_t st) {
         const char *e = getenv("EDV_GEMM_PLAIN");  // 1: one workgroup per tile even with a workspace (A/B runs)
         return e && atoi(e) != 0;
     }();
+    static const bool buf_off = [] {
+        const char *e = getenv("EDV_GEMM_BUF");  // 0: flat 64-bit DMA source addresses as in round 1 (A/B runs)
+        return e && atoi(e) == 0;
+    }();
+    const bool buf = !buf_off && fits_buffer(d);
     GemmSplit sp{1, 1, 0, 1, 0, nullptr, nullptr};
     long long grid = tiles;
     const int slots = dma_slots<STORE, EP>();
@@ -284,11 +342,13 @@ int launch_dma(const GemmDesc &d, long long tiles, hipStream_t st) {
         sp.ws = d.ws + MAX_COUNTERS;
         EDV_CHECK((size_t)MAX_COUNTERS + (size_t)sp.nsplit * 2 * SLOT <= d.ws_floats && (uintptr_t)d.ws % 16 == 0,
                   "stream-K workspace too small (gemm_workspace)");
-        hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP, true>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
+        if (buf) hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP, true, true>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
+        else hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP, true, false>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
         EDV_LAUNCH_OK();
         return 0;
     }
-    hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP, false>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
+    if (buf) hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP, false, true>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
+    else hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP, false, false>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
     EDV_LAUNCH_OK();
     return 0;
 }

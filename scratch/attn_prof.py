@@ -1,6 +1,6 @@
 """rocprofv3 target: the T=8 ViT-S attention launch, 50 times."""
 import sys, torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from endodav_amd import _lib
 lib = _lib.load(); dev = torch.device("cuda:0")
 F, N, heads = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (8, 1370, 6)

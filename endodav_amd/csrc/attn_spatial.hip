@@ -259,7 +259,6 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_kernel(const float *__re
 //     advance sits in the SCALAR offset, rows past the sequence end fall outside the descriptor and read as zeros; two LDS stages per
 //     operand and a loop unrolled by two make every fragment address a register + immediate: no address arithmetic in the loop, one
 //     barrier per tile.  K rows are XOR-swizzled 256-byte lines (b128 reads down a column), V rows are linear (b32 reads along a row).
-// (not a template: hipcc 7.2 silently fails to instantiate the host stub of a kernel TEMPLATE whose body holds this generic lambda)
 constexpr int LEAN_NW = 4;
 __global__ __launch_bounds__(LEAN_NW * 64, 2) void attn_lean_kernel(const float *__restrict__ qkv, float *__restrict__ out, float *__restrict__ ws,
                                                                float *__restrict__ lse, int N, int heads, int whole_rounds, long long units, int chunk) {
@@ -348,7 +347,7 @@ __global__ __launch_bounds__(LEAN_NW * 64, 2) void attn_lean_kernel(const float 
             const int soff = ((t * KT) * D3 + which * D + head * HD) * 4;
 #pragma unroll
             for (int i = 0; i < RPW / 4; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(dst + 4 * i * HD), 16, which == 1 ? vk[i] : vv[i], soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void *)(dst + 4 * i * HD), 16, (unsigned)(which == 1 ? vk[i] : vv[i]), (int)soff, 0, 0);
         };
         f32x16 o0, o1;
 #pragma unroll

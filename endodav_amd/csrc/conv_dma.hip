@@ -8,7 +8,15 @@
 // ResidualConvUnits is applied to the A fragments after the LDS read (4 v_max per 4 MFMAs).
 //
 // LDS image, swizzle and pipeline are those of gemm_dma.hip.  Tiles: 64x64 (2x2 waves) or, for Cout <= 32, 128x32 (4x1).
+//
+// Round 2 (BUF = true, operands within 4 GB): the k loop of gemm_dma.hip -- DMA through buffer descriptors with the tap / channel advance
+// in the SCALAR offset, scalar wave index, loop unrolled by two so that the LDS stage is an immediate -- because the f32 MFMA and the
+// VALU do not overlap on this part.  A padding tap is a lane whose byte offset is switched to one past the descriptor's range: an
+// out-of-range lane of a buffer LDS-DMA writes zeros into LDS (checked on the part, scratch/ubench/README), so no zero page is read.
+// What is left per k-tile: one compare + select per A-side DMA (is this lane's tap inside the image?) and, with pre_relu, the v_max of
+// the A fragments.
 #include <cstdlib>
+#include <type_traits>
 
 #include "gemm_common.hpp"
 
@@ -22,7 +30,7 @@ __device__ __attribute__((aligned(256))) float g_zero_page[64];
 // tiles of 108 k-tiles on 256 CUs): the tiles' k-tile units are cut into equal contiguous runs, one per workgroup; a run that does
 // not cover a tile's whole k range leaves its accumulators in a workspace slot and the last piece of a tile to arrive merges them in
 // run order and applies the epilogue.  SPLIT = false is the plain grid and compiles to the code it was before.
-template <int WGM, int EP, bool SPLIT>
+template <int WGM, int EP, bool SPLIT, bool BUF>
 __global__ __launch_bounds__(256) void conv3_dma_kernel(const GemmDesc g, const GemmSplit sp) {
     constexpr int WGN = 4 / WGM;
     constexpr int BM = 32 * WGM, BN = 32 * WGN;
@@ -30,16 +38,21 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const GemmDesc g, const 
     constexpr int STAGE = (BM + BN) * CBK;
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
+    const int wave_s = __builtin_amdgcn_readfirstlane(wave);
+    const bool prelu = g.pre_relu != 0;
     const int wm = wave / WGN, wn = wave % WGN;
     const int tiles_n = (g.N + BN - 1) / BN;
     const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    // BUF: descriptors over the input tensor (exactly its bytes: a lane sent past the end reads zeros) and the packed weight
+    const unsigned a_bytes = BUF ? (unsigned)((g.M > 0 ? ((g.M - 1) / (g.cOH * g.cOW) + 1) : 0) * (long long)g.cH * g.cW * g.cC * 4) : 0u;
+    const auto rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.A), 0, a_bytes, 0x00020000);
+    const auto rW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.W), 0, 0xffffffff, 0x00020000);
     const int srow = lane >> 3, spos = lane & 7;
     const float *zero = g_zero_page + spos * 4;
     const int opix = g.cOH * g.cOW;
     const int nkt = g.K / CBK;
     const int ra = wm * 32 + l31, rb = wn * 32 + l31;
     const int swa = (ra >> 1) & 7, swb = (rb >> 1) & 7;
-    const bool prelu = g.pre_relu != 0;
 
     // SPLIT: run `bid` of the split (stride 1: every workgroup of the grid owns one); plain: one whole tile
     long long u = SPLIT ? (long long)bid * sp.chunk : 0;
@@ -71,6 +84,7 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const GemmDesc g, const 
 
         // per-lane A rows: output pixel -> pointer to the (dy, dx) = (0, 0) tap of its window, validity bits per dy and dx
         const float *pa[IA];
+        unsigned va[IA], vb[IB];  // BUF: byte offsets (A: of the window's centre tap)
         int okmask[IA];  // bits 0..2: row iy0 + dy inside the image; bits 3..5: column ix0 + dx inside
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
@@ -83,6 +97,7 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const GemmDesc g, const 
             const int oy = p / g.cOW, ox = p - oy * g.cOW;
             const int iy0 = oy * g.cS - 1, ix0 = ox * g.cS - 1;
             pa[i] = g.A + ((f * g.cH + iy0) * (long long)g.cW + ix0) * g.cC + c * 4;
+            va[i] = (unsigned)((((f * g.cH + iy0 + 1) * (long long)g.cW + ix0 + 1) * g.cC + c * 4) * 4);  // the window's CENTRE tap: always inside
             int mk = 0;
 #pragma unroll
             for (int d = 0; d < 3; ++d) {
@@ -99,25 +114,62 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const GemmDesc g, const 
             int n = n0 + r;
             n = n < g.N ? n : g.N - 1;
             pb[i] = g.W + (long long)n * g.ldw + c * 4;
+            vb[i] = (unsigned)(((long long)n * g.ldw + c * 4) * 4);
+        }
+        // tap state of the NEXT k-tile to stage (uniform; advanced by 32 channels per call instead of dividing k by Cin every time)
+        int n_c0, n_dy, n_dx;
+        {
+            const int k = kt0 * CBK, tap = k / g.cC;
+            n_c0 = k - tap * g.cC;
+            n_dy = tap / 3;
+            n_dx = tap - n_dy * 3;
         }
         auto issue = [&](int kt, int st) {
             float *sA = smem + st * STAGE, *sB = sA + BM * CBK;
             const int k = kt * CBK;
-            const int tap = k / g.cC, c0 = k - tap * g.cC;  // uniform: the whole k-tile lies inside one tap
-            const int dy = tap / 3, dx = tap - dy * 3;
+            const int dy = n_dy, dx = n_dx, c0 = n_c0;
+            n_c0 += CBK;
+            if (n_c0 == g.cC) {
+                n_c0 = 0;
+                if (++n_dx == 3) {
+                    n_dx = 0;
+                    ++n_dy;
+                }
+            }
             const long long off = ((long long)dy * g.cW + dx) * g.cC + c0;
             const int need = (1 << dy) | (8 << dx);
 #pragma unroll
             for (int i = 0; i < IA; ++i) {
-                const float *src = (okmask[i] & need) == need ? pa[i] + off : zero;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
-                                                 (__attribute__((address_space(3))) void *)(sA + ((BM / 4) * wave + 8 * i) * CBK), 16, 0, 0);
+                if constexpr (BUF) {
+                    // valid tap: the centre tap's byte offset plus the tap's (signed, uniform) distance from it -- the sum is formed here, in 32
+                    // bits, because the descriptor path adds voffset + soffset without wrapping; the channel advance rides in the scalar
+                    // operand.  Padding tap: an offset beyond the descriptor -> the lane writes zeros.
+                    const int delta = (((dy - 1) * g.cW + (dx - 1)) * g.cC) * 4;
+                    const unsigned vo = (okmask[i] & need) == need ? va[i] + (unsigned)delta : 0x80000000u + a_bytes;
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void *)(sA + ((BM / 4) * wave_s + 8 * i) * CBK), 16, (unsigned)vo,
+                                                             (int)(c0 * 4), 0, 0);
+                } else {
+                    const float *src = (okmask[i] & need) == need ? pa[i] + off : zero;
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                                     (__attribute__((address_space(3))) void *)(sA + ((BM / 4) * wave + 8 * i) * CBK), 16, 0, 0);
+                }
             }
 #pragma unroll
-            for (int i = 0; i < IB; ++i)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pb[i] + k),
-                                                 (__attribute__((address_space(3))) void *)(sB + ((BN / 4) * wave + 8 * i) * CBK), 16, 0, 0);
+            for (int i = 0; i < IB; ++i) {
+                if constexpr (BUF)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void *)(sB + ((BN / 4) * wave_s + 8 * i) * CBK), 16, (unsigned)vb[i], (int)(k * 4), 0,
+                                                             0);
+                else
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(pb[i] + k),
+                                                     (__attribute__((address_space(3))) void *)(sB + ((BN / 4) * wave + 8 * i) * CBK), 16, 0, 0);
+            }
         };
+        const float *fpa[4], *fpb[4];  // fragment read addresses in stage 0
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            fpa[q] = smem + ra * CBK + (((2 * q + lh) ^ swa) << 2);
+            fpb[q] = smem + BM * CBK + rb * CBK + (((2 * q + lh) ^ swb) << 2);
+        }
 
         EpiCols<1> cols;
         if (EP != 0) cols = gemm_epilogue_prefetch<1>(g, n0, wn * 32, l31);
@@ -128,24 +180,39 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const GemmDesc g, const 
         issue(kt0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        for (int kt = kt0; kt < kt1; ++kt) {
-            const int st = (kt - kt0) & 1;
-            if (kt + 1 < kt1) issue(kt + 1, st ^ 1);
-            const float *sA = smem + st * STAGE, *sB = sA + BM * CBK;
+        auto ktile = [&](int kt, auto st_tag) {
+            constexpr int ST = decltype(st_tag)::value;
+            if (kt + 1 < kt1) issue(kt + 1, ST ^ 1);
+            f32x4 fa[4], fb[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int cq = 2 * q + lh;
-                f32x4 fa = *reinterpret_cast<const f32x4 *>(&sA[ra * CBK + ((cq ^ swa) << 2)]);
-                const f32x4 fb = *reinterpret_cast<const f32x4 *>(&sB[rb * CBK + ((cq ^ swb) << 2)]);
-                if (prelu) {
-                    fa.x = fmaxf(fa.x, 0.f); fa.y = fmaxf(fa.y, 0.f); fa.z = fmaxf(fa.z, 0.f); fa.w = fmaxf(fa.w, 0.f);
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], acc[0][0], 0, 0, 0);
+                fa[q] = *reinterpret_cast<const f32x4 *>(fpa[q] + ST * STAGE);
+                fb[q] = *reinterpret_cast<const f32x4 *>(fpb[q] + ST * STAGE);
             }
+            __builtin_amdgcn_sched_barrier(0);  // all eight reads in flight before the first MFMA waits (gemm_dma.hip)
+            if (prelu) {  // one uniform branch per k-tile; one v_med3 per element: med3(x, 0, +inf) = max(x, 0) (fmaxf costs two instructions)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) fa[q][e] = __builtin_amdgcn_fmed3f(fa[q][e], 0.f, __builtin_inff());
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[q][e], fb[q][e], acc[0][0], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);  // the MFMAs stay above the wait for the next tile's DMA
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
+        };
+        {
+            int kt = kt0;
+            for (; kt + 1 < kt1; kt += 2) {
+                ktile(kt, std::integral_constant<int, 0>{});
+                ktile(kt + 1, std::integral_constant<int, 1>{});
+            }
+            if (kt < kt1) ktile(kt, std::integral_constant<int, 0>{});
         }
         if (SPLIT && part) {
             // the piece exchange of gemm_dma.hip: agent-scope relaxed atomics (sc1 write-through stores / L2-bypassing loads), an
@@ -197,16 +264,28 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const GemmDesc g, const 
     }
 }
 
+template <int WGM, int EP, bool SPLIT>
+void launch_variant(const GemmDesc &d, const GemmSplit &sp, bool buf, unsigned grid, hipStream_t st) {
+    if (buf) hipLaunchKernelGGL((conv3_dma_kernel<WGM, EP, SPLIT, true>), dim3(grid), dim3(256), 0, st, d, sp);
+    else hipLaunchKernelGGL((conv3_dma_kernel<WGM, EP, SPLIT, false>), dim3(grid), dim3(256), 0, st, d, sp);
+}
+
+// (Build note, hipcc 7.2: in the HOST pass an amdgcn builtin whose integer arguments need an implicit conversion from a captured lvalue makes
+// the kernel specialization silently invalid -- "no matching function" at the launch, or an undefined __device_stub__ at load time -- while
+// the device pass compiles it.  Hence the explicit (unsigned) / (int) casts on the buffer-load offsets.)
+template <int WGM, int EP>
+int conv_slots_query() {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    void (*kern)(const GemmDesc, const GemmSplit) = conv3_dma_kernel<WGM, EP, true, true>;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0) != hipSuccess) return 0;
+    if (per_cu > 4) per_cu = 4;  // 32 KB of LDS: the API says 5, the part places 4 (scratch/ubench/lds_residency.hip)
+    return cus * per_cu;
+}
 template <int WGM, int EP>
 int conv_slots() {
-    static const int slots = [] {
-        int dev = 0, cus = 0, per_cu = 0;
-        if (hipGetDevice(&dev) != hipSuccess) return 0;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, conv3_dma_kernel<WGM, EP, true>, 256, 0) != hipSuccess) return 0;
-        if (per_cu > 4) per_cu = 4;  // 32 KB of LDS: the API says 5, the part places 4 (scratch/ubench/lds_residency.hip)
-        return cus * per_cu;
-    }();
+    static const int slots = conv_slots_query<WGM, EP>();
     return slots;
 }
 
@@ -216,6 +295,13 @@ int launch_conv_ep(const GemmDesc &d, long long tiles, hipStream_t st) {
         const char *e = getenv("EDV_CONV_SPLIT");  // 0: plain grid always (A/B runs)
         return !(e && atoi(e) == 0);
     }();
+    static const bool buf_off = [] {
+        const char *e = getenv("EDV_CONV_BUF");  // 0: flat 64-bit DMA source addresses + zero page as in round 1 (A/B runs)
+        return e && atoi(e) == 0;
+    }();
+    // 32-bit byte offsets must reach every tap of every pixel, with room for the "beyond the end" offset of padding lanes
+    const long long frames = (d.M - 1) / ((long long)d.cOH * d.cOW) + 1;
+    const bool buf = !buf_off && frames * d.cH * d.cW * d.cC * 4 < (1ll << 31) - (1 << 20) && (long long)d.N * d.ldw * 4 < (1ll << 32) - (1 << 20);
     const int nkt = d.K / CBK;
     GemmSplit sp{0, 1, 0, 1, 0, nullptr, nullptr};
     const int slots = conv_slots<WGM, EP>();
@@ -234,12 +320,12 @@ int launch_conv_ep(const GemmDesc &d, long long tiles, hipStream_t st) {
         sp.cnt = reinterpret_cast<int *>(d.ws);
         sp.ws = d.ws + SPLIT_MAX_COUNTERS;
         if ((size_t)SPLIT_MAX_COUNTERS + (size_t)sp.nsplit * 2 * SPLIT_SLOT <= d.ws_floats && (uintptr_t)d.ws % 16 == 0) {
-            hipLaunchKernelGGL((conv3_dma_kernel<WGM, EP, true>), dim3((unsigned)sp.nsplit), dim3(256), 0, st, d, sp);
+            launch_variant<WGM, EP, true>(d, sp, buf, (unsigned)sp.nsplit, st);
             EDV_LAUNCH_OK();
             return 0;
         }
     }
-    hipLaunchKernelGGL((conv3_dma_kernel<WGM, EP, false>), dim3((unsigned)tiles), dim3(256), 0, st, d, sp);
+    launch_variant<WGM, EP, false>(d, sp, buf, (unsigned)tiles, st);
     EDV_LAUNCH_OK();
     return 0;
 }

@@ -133,10 +133,10 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g, const G
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 if constexpr (BUF) {
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void *)(sA + (16 * wave_s + 8 * i) * DBK), 16, va[i],
-                                                             kt * (DBK * 4), 0, 0);
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void *)(sB + (16 * wave_s + 8 * i) * DBK), 16, vb[i],
-                                                             kt * (DBK * 4), 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (__attribute__((address_space(3))) void *)(sA + (16 * wave_s + 8 * i) * DBK), 16, (unsigned)va[i],
+                                                             (int)(kt * (DBK * 4)), 0, 0);
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rW, (__attribute__((address_space(3))) void *)(sB + (16 * wave_s + 8 * i) * DBK), 16, (unsigned)vb[i],
+                                                             (int)(kt * (DBK * 4)), 0, 0);
                 } else {
                     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ga[i] + kt * DBK),
                                                      (__attribute__((address_space(3))) void *)(sA + (16 * wave + 8 * i) * DBK), 16, 0, 0);

@@ -200,11 +200,22 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g, const G
         }
         EDV_GEMM_STAMP(3);
         if (SPLIT && part) {
-            // Pieces travel between workgroups on different XCDs (separate L2s).  An agent-scope release / acquire fence pair
-            // would do it, but on this part the release writes back the WHOLE L2 (buffer_wbl2) -- measured +140 us per launch
-            // with every other workgroup's output tiles dirty in it.  Instead the piece itself is written and read with
-            // agent-scope relaxed atomics = write-through stores / L2-bypassing loads (sc1), and the arrival is counted after
-            // s_waitcnt vmcnt(0) has seen those stores acknowledged.
+            // Piece hand-off.  Pieces travel between workgroups on different XCDs (separate L2s, non-coherent L1s).  An agent-scope
+            // release / acquire fence pair would do it, but on this part the release writes back the WHOLE L2 (buffer_wbl2) -- measured
+            // +140 us per launch with every other workgroup's output tiles dirty in it.  Instead:
+            //   producer  every piece word is stored with an agent-scope relaxed atomic store (global_store ... sc1: write-through);
+            //             every storing wave then executes s_waitcnt vmcnt(0) (its stores are acknowledged), the workgroup meets at a
+            //             barrier, and ONE lane adds 1 to the tile's agent-scope counter;
+            //   consumer  the workgroup whose add returns "all pieces in" broadcasts that through LDS behind a workgroup barrier and
+            //             reads every piece word with agent-scope relaxed atomic loads (global_load ... sc1: served by L2, never by this
+            //             CU's L1), in run order whatever the arrival order was.
+            // This is the "sc1 stores + drained counter + sc1 loads" hand-off the CDNA4 guide measures as valid (MI355X_MICROARCH.md,
+            // Workgroup dispatch ..., Valid forms: one lane signals for all of its workgroup's stores after every wave's vmcnt(0) and
+            // the barrier; every load of the handed-off bytes is an sc1 load issued after the add has returned and a barrier).  It is
+            // an ISA-level contract of gfx950 / ROCm 7.2, NOT a guarantee of the C++ memory model: the __syncthreads() between the
+            // counter add and the loads is what keeps the compiler from hoisting the loads (a workgroup-scope fence), the hardware
+            // ordering comes from sc1.  tests/test_streamk_fuzz_gpu.py::test_piece_exchange_contract_under_uneven_load is the gate to
+            // re-run after a toolchain change; the fenced form to switch to is spelled out there.
 #pragma unroll
             for (int r = 0; r < 16; ++r) __hip_atomic_store(&part[(wave * 16 + r) * 64 + lane], acc[0][0][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // pieces of leftover tile lt: the runs whose unit ranges intersect [lt * nkt, (lt + 1) * nkt)

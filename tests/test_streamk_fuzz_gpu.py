@@ -164,3 +164,45 @@ def test_temporal_attention_forward_backward_sweep(lib, cuda, Bc, T, P, Cc):
     dqkv = torch.full((Bc * T * P, 3 * Cc), float("nan"), device=cuda)
     _lib.check(lib.edv_attn_temporal_bwd(qd.data_ptr(), gd.data_ptr(), dqkv.data_ptr(), Bc, T, P, Cc, heads, st()), "edv_attn_temporal_bwd")
     assert (dqkv.cpu().double() - dref).abs().max().item() <= 1e-5 * dref.abs().max().item()
+
+
+def test_piece_exchange_contract_under_uneven_load(lib, cuda, ws):
+    """The contract the in-kernel piece exchange of the split GEMM rests on (gemm_dma.hip, "piece hand-off"): pieces are written with
+    agent-scope (sc1, write-through) stores, each storing wave drains them (s_waitcnt vmcnt(0)) before the workgroup barrier behind which
+    ONE lane bumps the tile's agent-scope counter, and the last arriver reads the pieces with agent-scope (L2-served, L1-bypassing) loads
+    behind a workgroup barrier that follows its own counter add.  That is a row of the guide's measured hand-off table, not a C++ memory-model
+    guarantee, so this test is the gate to re-run after any ROCm / hipcc change.  It stresses what hides a broken hand-off: UNEVEN load (a
+    second stream keeps part of the chip busy with launches of other sizes, so pieces of a tile arrive far apart and their producers sit on
+    different XCDs), a consumer that has the piece slots warm in its caches (the workspace is poisoned with NaN between launches through
+    the same CUs, and every launch re-uses the same slots), and a check of every output word of 200 launches against the first.
+    If it ever fails: switch the hand-off to the fenced form (lane 0: __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent") + s_waitcnt vmcnt(0)
+    before the counter add; last arriver: __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent") + s_waitcnt vmcnt(0) + barrier before plain loads),
+    or set EDV_GEMM_STREAMK=0 (one workgroup per tile, no exchange) until it is."""
+    w, nbytes = ws
+    g = torch.Generator().manual_seed(11)
+    M, N, K = 10960, 384, 1536  # fc2 of ViT-S at T=8: 1032 tiles on 768 persistent workgroups, 264 leftover tiles split along K
+    A = torch.randn(M, K, generator=g).to(cuda)
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(cuda)
+    b = torch.randn(N, generator=g).to(cuda)
+    R = torch.randn(M, N, generator=g).to(cuda)
+    ref = (A.double() @ W.double().T + b.double() + R.double())
+    side = torch.cuda.Stream(device=cuda)
+    noise_a = [torch.randn(m, 512, device=cuda) for m in (300, 1700, 5000, 900)]
+    noise_w = torch.randn(512, 512, device=cuda) / math.sqrt(512)
+    first = None
+    for it in range(200):
+        w[COUNTER_FLOATS:] = float("nan")  # poison the piece slots (the counters stay: every launch must leave them at zero)
+        with torch.cuda.stream(side):      # uneven background load of other shapes on another stream
+            for a in noise_a[it % 4:] + noise_a[:it % 4]:
+                torch.matmul(a, noise_w)
+        Cd = torch.empty((M, N), device=cuda)
+        _lib.check(lib.edv_gemm(A.data_ptr(), W.data_ptr(), Cd.data_ptr(), M, N, K, b.data_ptr(), 0, None, R.data_ptr(), w.data_ptr(), nbytes, st()), "edv_gemm")
+        if first is None:
+            torch.cuda.synchronize()
+            first = Cd
+            err = (Cd.double() - ref).abs().max().item() / ref.abs().max().item()
+            assert err <= 3e-6, err
+        else:
+            assert torch.equal(Cd, first), f"launch {it}: a merged tile differs (torn or stale piece)"
+    torch.cuda.synchronize()
+    assert int(w[:COUNTER_FLOATS].view(torch.int32).abs().sum()) == 0

@@ -49,8 +49,13 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const float *__restrict
 }
 
 // NW waves (32 resident rows each) per workgroup share the streamed tiles
+// VALU diet (round 2; on this part the f32 MFMA and the VALU do not overlap: attn_spatial.hip, gemm_dma.hip): the score accumulators start
+// at -L and the dP accumulators at -delta, so the MFMA itself delivers X1 - L and dP - delta (32 subtractions per tile gone); the
+// sequence-end mask is a branch taken on the last tile only (it was 32 compare / select pairs on every tile); and all registers
+// live in the VGPR file (__launch_bounds__(.., 2): the compiler had parked the output accumulators in AGPRs and moved them on
+// every use).
 template <int MODE, int NW>
-__global__ __launch_bounds__(NW * 64) void attn_spatial_bwd_kernel(const float *__restrict__ qkv, const float *__restrict__ dO, const float *__restrict__ lse,
+__global__ __launch_bounds__(NW * 64, 2) void attn_spatial_bwd_kernel(const float *__restrict__ qkv, const float *__restrict__ dO, const float *__restrict__ lse,
                                                                const float *__restrict__ delta, float *__restrict__ dqkv, float *__restrict__ ws, int N,
                                                                int heads, int whole_rounds, long long units, int chunk) {
     __shared__ __attribute__((aligned(16))) float sT1[TR * TS];
@@ -177,10 +182,27 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_bwd_kernel(const float *
         __syncthreads();
         if (t + 1 < kt1) load_tile(t0 + TR);
 
-        // ---- X1^T = T1 R1^T (scores, base-2 logits), X2^T = T2 R2^T (dP)
+        // ---- X1^T - L = T1 R1^T - L (scores, base-2 logits), X2^T - delta = T2 R2^T - delta (dP): L / delta enter as the accumulators' start
+        // values.  Register r of lane-half h is streamed row (r&3) + 8*(r>>2) + 4*h; the resident row sits on the lane.
         f32x16 x1, x2;
+        if (MODE == MODE_DQ) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) x1[r] = x2[r] = 0.f;
+            for (int r = 0; r < 16; ++r) {
+                x1[r] = -Lq;
+                x2[r] = -Dq;
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f32x4 L4 = *reinterpret_cast<const f32x4 *>(&sL[8 * g + 4 * lh]);
+                const f32x4 D4 = *reinterpret_cast<const f32x4 *>(&sD[8 * g + 4 * lh]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    x1[4 * g + e] = -L4[e];
+                    x2[4 * g + e] = -D4[e];
+                }
+            }
+        }
 #pragma unroll
         for (int qq = 0; qq < 8; ++qq) {
             const f32x4 a1 = *reinterpret_cast<const f32x4 *>(&sT1[l31 * TS + 8 * qq + 4 * lh]);
@@ -191,28 +213,17 @@ __global__ __launch_bounds__(NW * 64) void attn_spatial_bwd_kernel(const float *
                 x2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a2[e], r2f[qq][e], x2, 0, 0, 0);
             }
         }
-        // ---- P = exp2(X1 - L), dS = P (dP - delta); register r of lane-half h is streamed row (r&3) + 8*(r>>2) + 4*h
-        if (MODE == MODE_DQ) {
+        if (t0 + TR > N) {  // streamed rows past the sequence end (last tile only; the empty asm keeps this a real branch): P = exp2(-inf) = 0
+            asm volatile("" ::: "memory");
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int trow = t0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float p = trow < N ? __builtin_amdgcn_exp2f(x1[r] - Lq) : 0.f;
-                x2[r] = p * (x2[r] - Dq);  // dS
-            }
-        } else {
+            for (int r = 0; r < 16; ++r)
+                if (t0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= N) x1[r] = -INFINITY;
+        }
+        // ---- P = exp2(X1 - L), dS = P (dP - delta)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const f32x4 L4 = *reinterpret_cast<const f32x4 *>(&sL[8 * g + 4 * lh]);
-                const f32x4 D4 = *reinterpret_cast<const f32x4 *>(&sD[8 * g + 4 * lh]);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g + e;
-                    const int trow = t0 + 8 * g + 4 * lh + e;
-                    const float p = trow < N ? __builtin_amdgcn_exp2f(x1[r] - L4[e]) : 0.f;
-                    x1[r] = p;                    // P
-                    x2[r] = p * (x2[r] - D4[e]);  // dS
-                }
-            }
+        for (int r = 0; r < 16; ++r) {
+            x1[r] = __builtin_amdgcn_exp2f(x1[r]);  // P
+            x2[r] = x1[r] * x2[r];                  // dS
         }
         // ---- third products: streamed rows contract; step r uses rows {row(r,0), row(r,1)} in its two k-slots
 #pragma unroll

@@ -240,7 +240,7 @@ def main():
         if n > 0 and ms > 0:
             achieved = flops / (ms / n * 1e-3) / 1e12
             rec, src = measured_traffic(args.encoder, T, (SH, SW), Bc, "attn")
-            roofline_attn = {"kernel": "attn_spatial_kernel (one encoder-block attention call)", "bound": "mfma",
+            roofline_attn = {"kernel": "attn_lean_kernel + attn_combine_kernel (one encoder-block attention call)", "bound": "mfma",
                              "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None if rec is None else rec["traffic_bytes_per_launch"],
                              "traffic_unit": None if rec is None else f"bytes per call (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, {src})",

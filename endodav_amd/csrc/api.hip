@@ -48,33 +48,6 @@ int edv_conv3x3_ws(const float *x_dev, const float *wpacked_dev, const float *bi
                         workspace_bytes, stream);
 }
 
-int edv_gemm_sb(const float *A_dev, const float *W_dev, void *wplanes_dev, float *C_dev, int64_t M, int32_t N, int32_t K, const float *bias_dev,
-                int32_t act, const float *gamma_dev, const float *R_dev, void *stream) {
-    EDV_CHECK(wplanes_dev, "null plane scratch");
-    EDV_CHECK(act >= ACT_NONE && act <= ACT_RELU, "act must be 0, 1 or 2");
-    EDV_TRY(split_planes(W_dev, (unsigned short *)wplanes_dev, (long long)N * K, (hipStream_t)stream));
-    GemmDesc g;
-    g.A = A_dev; g.lda = K; g.W = W_dev; g.ldw = K; g.Wsb = (const unsigned short *)wplanes_dev; g.wsb_plane = (long long)N * K;
-    g.C = C_dev; g.ldc = N; g.M = M; g.N = N; g.K = K;
-    g.bias = bias_dev; g.act = act; g.gamma = gamma_dev; g.R1 = R_dev; g.ldr1 = N;
-    return gemm_sb(g, (hipStream_t)stream);
-}
-
-int edv_conv3x3_sb(const float *x_dev, const float *wpacked_dev, void *wplanes_dev, const float *bias_dev, float *y_dev, int32_t F, int32_t H, int32_t W,
-                   int32_t Cin, int32_t Cout, int32_t stride, int32_t pre_relu, int32_t post_relu, const float *R1_dev, const float *R2_dev,
-                   void *stream) {
-    EDV_CHECK(F > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0 && wplanes_dev, "bad argument");
-    EDV_CHECK(stride == 1 || stride == 2, "stride must be 1 or 2");
-    EDV_TRY(split_planes(wpacked_dev, (unsigned short *)wplanes_dev, (long long)Cout * 9 * Cin, (hipStream_t)stream));
-    GemmDesc g;
-    const int OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
-    g.A = x_dev; g.W = wpacked_dev; g.ldw = 9 * Cin; g.Wsb = (const unsigned short *)wplanes_dev; g.wsb_plane = (long long)Cout * 9 * Cin;
-    g.C = y_dev; g.ldc = Cout; g.M = (long long)F * OH * OW; g.N = Cout; g.K = 9 * Cin;
-    g.bias = bias_dev; g.act = post_relu ? ACT_RELU : ACT_NONE; g.R1 = R1_dev; g.ldr1 = Cout; g.R2 = R2_dev; g.ldr2 = Cout;
-    g.loader = LOAD_CONV3; g.cH = H; g.cW = W; g.cC = Cin; g.cOH = OH; g.cOW = OW; g.cS = stride; g.pre_relu = pre_relu ? 1 : 0;
-    return gemm_sb(g, (hipStream_t)stream);
-}
-
 int edv_pack_conv3x3(const float *w_dev, float *wpacked_dev, int32_t Cout, int32_t Cin, void *stream) {
     return pack_conv3x3(w_dev, wpacked_dev, Cout, Cin, (hipStream_t)stream);
 }

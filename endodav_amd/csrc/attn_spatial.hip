@@ -41,6 +41,7 @@ namespace {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
+using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 constexpr int HD = 64;       // head dim
 constexpr int KS = HD + 4;   // padded K row stride: 68r mod 64 = 4r -> conflict-free b128
@@ -388,9 +389,15 @@ __global__ __launch_bounds__(LEAN_NW * 64, 2) void attn_lean_kernel(const float 
                     if (k0 + 32 + (r & 3) + 8 * (r >> 2) + 4 * lh >= N) s1[r] = -INFINITY;
                 }
             }
-            float mx = fmaxf(s0[0], s1[0]);
+            // two chains of three-way maxima (v_max3_f32): 17 instructions for the 32 scores.  This file is compiled with -fno-honor-nans
+            // (Makefile): otherwise every MFMA result is first "canonicalised" with a v_max_f32 x, x of its own, 57 instructions instead.
+            float mx = fmaxf(s0[0], s1[0]), my = fmaxf(s0[8], s1[8]);
 #pragma unroll
-            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+            for (int r = 1; r < 8; ++r) {
+                mx = fmaxf(fmaxf(mx, s0[r]), s1[r]);
+                my = fmaxf(fmaxf(my, s0[r + 8]), s1[r + 8]);
+            }
+            mx = fmaxf(mx, my);
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             // rebase?  (wave-uniform decision; each lane then moves by its own amount)
             if (FIRST || __builtin_amdgcn_ballot_w64(mx > TAU) != 0) {
@@ -406,18 +413,21 @@ __global__ __launch_bounds__(LEAN_NW * 64, 2) void attn_lean_kernel(const float 
                     o1[r] *= alpha;
                 }
             }
-            float psum = 0.f;
+            // row sums two at a time (v_pk_add_f32: 16 instructions for 32 addends)
+            f32x2 psum = {0.f, 0.f};
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < 16; r += 2) {
                 s0[r] = __builtin_amdgcn_exp2f(s0[r]);
-                psum += s0[r];
+                s0[r + 1] = __builtin_amdgcn_exp2f(s0[r + 1]);
+                psum += f32x2{s0[r], s0[r + 1]};
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
+            for (int r = 0; r < 16; r += 2) {
                 s1[r] = __builtin_amdgcn_exp2f(s1[r]);
-                psum += s1[r];
+                s1[r + 1] = __builtin_amdgcn_exp2f(s1[r + 1]);
+                psum += f32x2{s1[r], s1[r + 1]};
             }
-            l_run += psum;
+            l_run += psum[0] + psum[1];
             // ---- O^T += V^T P^T: register r of lane-half h of sub-tile u is key 32 u + (r&3) + 8 (r>>2) + 4 h
 #pragma unroll
             for (int r = 0; r < 16; ++r) {

@@ -1,4 +1,4 @@
-// Pieces shared by the fp32-MFMA GEMM (gemm.hip) and the split-bf16 GEMM (gemm_sb.hip): both accumulate 32x32
+// Pieces shared by the fp32-MFMA GEMMs (gemm.hip, gemm_dma.hip, conv_dma.hip; experiments/gemm_sb.hip used them too): all accumulate 32x32
 // tiles whose C/D register layout is  col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)  (dtype-independent on gfx950).
 #pragma once
 #include "ops.hpp"

@@ -25,8 +25,6 @@ struct GemmDesc {
     RowMap a_map{0, 0, 0};
     const float *W = nullptr;
     int ldw = 0;
-    const unsigned short *Wsb = nullptr;  // W pre-split into three bf16 planes (same [N, ldw] layout each), gemm_sb only
-    long long wsb_plane = 0;              // elements between planes
     float *C = nullptr;
     int ldc = 0;
     RowMap c_map{0, 0, 0};
@@ -62,10 +60,6 @@ int gemm_dma(const GemmDesc &d, hipStream_t st);
 // LDS-DMA implicit-GEMM 3x3 convolution (conv_dma.hip): Cin % 32 == 0, any stride the GemmDesc allows
 bool conv_dma_supported(const GemmDesc &d);
 int conv_dma(const GemmDesc &d, hipStream_t st);
-// Split-bf16 variant (gemm_sb.hip): same contract, fp32-equivalent accuracy from six bf16 MFMAs per product.
-bool gemm_sb_supported(const GemmDesc &d);
-int gemm_sb(const GemmDesc &d, hipStream_t st);
-int split_planes(const float *w, unsigned short *out, long long n, hipStream_t st);  // out: 3 planes of n bf16
 // flops of the last-launched gemm tile choice, for the bench's roofline bookkeeping
 const char *gemm_kernel_name(const GemmDesc &d);
 

@@ -149,16 +149,6 @@ int edv_gemm(const float *A_dev, const float *W_dev, float *C_dev, int64_t M, in
  * (it starts with per-tile arrival counters, which every launch leaves at zero).  workspace_dev = NULL: one workgroup per tile. */
 size_t edv_gemm_workspace(void);
 
-/* Split-bf16 variant of edv_gemm: fp32-equivalent accuracy from six v_mfma_f32_32x32x16_bf16 per product (each
- * operand = exact sum of three bf16 pieces).  wplanes_dev: caller scratch of 3*N*K bf16 (6*N*K bytes) that receives the
- * split W.  Needs K % 8 == 0. */
-int edv_gemm_sb(const float *A_dev, const float *W_dev, void *wplanes_dev, float *C_dev, int64_t M, int32_t N, int32_t K, const float *bias_dev,
-                int32_t act, const float *gamma_dev, const float *R_dev, void *stream);
-/* Split-bf16 variant of edv_conv3x3; wplanes_dev: 3*Cout*9*Cin bf16 of scratch. */
-int edv_conv3x3_sb(const float *x_dev, const float *wpacked_dev, void *wplanes_dev, const float *bias_dev, float *y_dev, int32_t F, int32_t H, int32_t W,
-                   int32_t Cin, int32_t Cout, int32_t stride, int32_t pre_relu, int32_t post_relu, const float *R1_dev, const float *R2_dev,
-                   void *stream);
-
 /* 3x3 convolution, padding 1, stride 1 or 2, channels-last: x [F,H,W,Cin], w packed
  * [Cout][3][3][Cin], y [F,OH,OW,Cout]; optional ReLU on the input (util/blocks.py:79-85),
  * bias, ReLU on the output and up to two residual tensors shaped like y. */

@@ -117,49 +117,6 @@ def test_gemm(lib, cuda, M, N, K, act, use_bias, use_gamma, use_res, split):
     close(Cd, ref, 3e-6, f"gemm {M}x{N}x{K}")
 
 
-@pytest.mark.parametrize("M,N,K,act,use_bias,use_gamma,use_res", [
-    (2 * 1370, 1152, 384, 0, True, False, False),
-    (2 * 1370, 384, 1536, 0, True, True, True),
-    (1370, 1536, 384, 1, True, False, False),
-    (257, 48, 384, 0, True, False, False),
-    (1000, 32, 144, 2, True, False, False),     # 256x32 tile
-    (999, 16, 64, 0, False, False, False),
-    (3, 96, 96, 0, True, False, False),
-    (5000, 768, 48, 0, True, False, False),      # K = 48: one full 32-k tile + a 16-k tail
-    (4096, 512, 1000, 0, True, False, False),    # K tail of 8
-])
-def test_gemm_split_bf16(lib, cuda, M, N, K, act, use_bias, use_gamma, use_res):
-    """The six-product bf16 emulation must be as accurate as the fp32 MFMA path (same tolerance)."""
-    A, W = rnd(M, K, seed=1, scale=3.0), rnd(N, K, seed=2, scale=1 / math.sqrt(K))
-    A[0, :] *= 1e-3  # mixed magnitudes within one dot product
-    A[:, 0] *= 50.0
-    bias = rnd(N, seed=3, scale=0.1) if use_bias else None
-    gamma = rnd(N, seed=4) + 1.2 if use_gamma else None
-    R = rnd(M, N, seed=5) if use_res else None
-    ref = A.double() @ W.double().T
-    if bias is not None:
-        ref = ref + bias.double()
-    ref = F.gelu(ref) if act == 1 else (F.relu(ref) if act == 2 else ref)
-    if gamma is not None:
-        ref = ref * gamma.double()
-    if R is not None:
-        ref = ref + R.double()
-    d = lambda t: None if t is None else t.to(cuda)
-    Ad, Wd, bd, gd, Rd = d(A), d(W), d(bias), d(gamma), d(R)
-    planes = torch.empty(3 * N * K, dtype=torch.bfloat16, device=cuda)
-    Cd = torch.full((M, N), float("nan"), device=cuda)
-    _lib.check(lib.edv_gemm_sb(Ad.data_ptr(), Wd.data_ptr(), planes.data_ptr(), Cd.data_ptr(), M, N, K, _lib.ptr(bd), act, _lib.ptr(gd), _lib.ptr(Rd), st()),
-               "edv_gemm_sb")
-    e_sb = close(Cd, ref, 3e-6, f"gemm_sb {M}x{N}x{K}")
-    Cf = torch.empty((M, N), device=cuda)
-    _lib.check(lib.edv_gemm(Ad.data_ptr(), Wd.data_ptr(), Cf.data_ptr(), M, N, K, _lib.ptr(bd), act, _lib.ptr(gd), _lib.ptr(Rd), None, 0, st()))
-    e_f32 = close(Cf, ref, 3e-6, "gemm f32")
-    print(f"\n[{M}x{N}x{K}] error vs fp64: split-bf16 {e_sb:.2e}, fp32 MFMA {e_f32:.2e}")
-    # the three planes reassemble W exactly
-    p = planes.float().reshape(3, N, K).sum(0)
-    assert torch.equal(p, Wd)
-
-
 @pytest.mark.parametrize("M,split", [(1370, False), (8 * 1370, True)], ids=["plain", "streamk"])
 def test_gemm_inplace_residual(lib, cuda, M, split):
     """proj / fc2 write the residual stream in place (C aliases R)."""
@@ -245,37 +202,6 @@ def test_conv3x3(lib, cuda, Fr, H, W, Cin, Cout, stride, pre, post, res, split):
     _lib.check(lib.edv_conv3x3(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), y.data_ptr(), Fr, H, W, Cin, Cout, stride, int(pre), int(post),
                                _lib.ptr(r1), _lib.ptr(r2), st()), "edv_conv3x3")
     close(y.permute(0, 3, 1, 2), ref, 3e-6, "conv3x3")
-
-
-@pytest.mark.parametrize("Fr,H,W,Cin,Cout,stride,pre,post,res", [
-    (2, 19, 23, 48, 64, 1, False, False, 0),
-    (2, 37, 37, 384, 384, 2, False, False, 0),
-    (3, 20, 16, 64, 64, 1, True, False, 2),
-    (1, 70, 98, 32, 32, 1, False, True, 0),
-    (2, 5, 7, 16, 32, 1, False, True, 0),
-])
-def test_conv3x3_split_bf16(lib, cuda, Fr, H, W, Cin, Cout, stride, pre, post, res):
-    x = rnd(Fr, Cin, H, W, seed=1, scale=2.0)
-    w = rnd(Cout, Cin, 3, 3, seed=2, scale=1 / math.sqrt(9 * Cin))
-    b = rnd(Cout, seed=3, scale=0.1)
-    ref = F.conv2d((F.relu(x) if pre else x).double(), w.double(), b.double(), stride=stride, padding=1)
-    if post:
-        ref = F.relu(ref)
-    OH, OW = ref.shape[-2:]
-    R1 = rnd(Fr, Cout, OH, OW, seed=4) if res >= 1 else None
-    R2 = rnd(Fr, Cout, OH, OW, seed=5) if res >= 2 else None
-    for r in (R1, R2):
-        if r is not None:
-            ref = ref + r.double()
-    nhwc = lambda t: None if t is None else t.permute(0, 2, 3, 1).contiguous().to(cuda)
-    xd, wd, bd, r1, r2 = nhwc(x), w.to(cuda), b.to(cuda), nhwc(R1), nhwc(R2)
-    wp = torch.empty(Cout * 9 * Cin, device=cuda)
-    planes = torch.empty(3 * Cout * 9 * Cin, dtype=torch.bfloat16, device=cuda)
-    _lib.check(lib.edv_pack_conv3x3(wd.data_ptr(), wp.data_ptr(), Cout, Cin, st()))
-    y = torch.full((Fr, OH, OW, Cout), float("nan"), device=cuda)
-    _lib.check(lib.edv_conv3x3_sb(xd.data_ptr(), wp.data_ptr(), planes.data_ptr(), bd.data_ptr(), y.data_ptr(), Fr, H, W, Cin, Cout, stride, int(pre),
-                                  int(post), _lib.ptr(r1), _lib.ptr(r2), st()), "edv_conv3x3_sb")
-    close(y.permute(0, 3, 1, 2), ref, 3e-6, "conv3x3_sb")
 
 
 @pytest.mark.parametrize("Fr,h,w,Cc,s", [(2, 37, 37, 48, 4), (2, 16, 20, 96, 2), (1, 3, 4, 32, 4)])

@@ -45,9 +45,22 @@ def test_real_video_run_with_native_resolution_resize(cuda):
     frames = (synth.synth_clip(1, 25, 60, 80, seed=4, kind="tissue")[0].transpose(0, 2, 3, 1) * 255).astype(np.uint8)
     out = model.infer_video_depth(frames, device="cuda:0")
     assert out.shape == (25, 60, 80) and np.isfinite(out).all() and (out >= 0).all() and out.max() > 0
-    # a one-window video needs no stitching: frame i must equal the direct forward on the resized clip
+    # 25 frames = two windows (the second one exercises the pipelined upload / download).  Stitching rewrites only the last INTERP_LEN = 8
+    # slots of window 0, so frames 0..23 must equal the direct forward on the HIP-resized clip of window 0, brought back to the frame size
+    # with torch's own bilinear (align_corners=True, endodav.py:203-204) -- the streams, the uint8 upload and the stitching add nothing
+    from endodav_amd import video
+
+    runner = video.HipWindowRunner(model, np.ascontiguousarray(frames), torch.device("cuda:0"))
+    sources = video.window_sources(25)
+    assert len(sources) == 2
+    x = runner.resized_clip(sources[0])
+    assert x.shape == (1, 32, 3, h, w)
+    with torch.no_grad():
+        disp = model(x)[("disp", 0)]  # [32, 1, h, w]
+        direct = torch.nn.functional.interpolate(disp, size=(60, 80), mode="bilinear", align_corners=True)[:24, 0].cpu().numpy()
+    assert np.abs(out[:24] - direct).max() <= 2e-6 * np.abs(direct).max()
     out2 = model.infer_video_depth(frames, device="cuda:0")
-    assert np.array_equal(out, out2)
+    assert np.array_equal(out, out2)  # and the pipelined run is reproducible bit for bit
 
 
 def test_evaluate_video_end_to_end(cuda):

@@ -51,12 +51,14 @@ constexpr int DSTAGE = (DBM + DBN) * DBK;  // floats per stage (16 KB)
 constexpr int SLOT = SPLIT_SLOT;
 constexpr int MAX_COUNTERS = SPLIT_MAX_COUNTERS;
 
-// Epilogue of a FULL 64x64 tile through buffer descriptors (EP = 1..3: identity row maps, compile-time activation).  The general form
+// Epilogue of a 64x64 tile through buffer descriptors (EP = 1..3: identity row maps, compile-time activation).  The general form
 // (gemm_epilogue_fast) spends ~20 VALU instructions per output register on 64-bit addresses, row-bound compares and exec masks -- a few
 // hundred per tile, and on this part every VALU instruction is matrix-pipe time (a K = 384 tile is only 192 MFMAs per wave).  Here the
 // per-lane offset (4 lh rows + column l31) is one multiply per tile and the row advance lives in the SCALAR offset of buffer_load /
 // buffer_store: the address arithmetic is SALU, the VALU work is the arithmetic the epilogue exists for (bias, activation, gamma, residual).
-// Edge tiles (rows past M or columns past N) take the general form.
+// Edge tiles need no second code path: the descriptors end at row M (num_records = M x ld x 4 bytes; the hardware range-checks voffset + soffset
+// as one sum without wrap-around -- scratch/ubench/buf_range.hip -- so stores to rows past M are dropped and loads return 0), and a lane whose
+// column is past N gets a per-lane offset near 2^32, which no scalar offset brings back into range.
 template <int ACT>
 __device__ __forceinline__ void gemm_epilogue_buf(const GemmDesc &g, f32x16 &acc, const EpiCols<1> &cols, long long m0, int n0, int wave_s, int l31, int lh) {
     using f32x2 = __attribute__((ext_vector_type(2))) float;
@@ -67,7 +69,7 @@ __device__ __forceinline__ void gemm_epilogue_buf(const GemmDesc &g, f32x16 &acc
 #pragma unroll
     for (int i = 0; i < 8; ++i) res[i] = f32x2{0.f, 0.f};
     if (g.R1) {
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.R1), 0, 0xffffffff, 0x00020000);
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.R1), 0, (int)(unsigned)(g.M * g.ldr1 * 4), 0x00020000);
         const unsigned vo = (unsigned)((4 * lh * g.ldr1 + l31) * 4);
         const unsigned so = (unsigned)((row0 * g.ldr1 + col0) * 4);
 #pragma unroll
@@ -75,15 +77,16 @@ __device__ __forceinline__ void gemm_epilogue_buf(const GemmDesc &g, f32x16 &acc
             res[r >> 1][r & 1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)vo, (int)(so + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldr1 * 4)), 0));
     }
     if (g.R2) {
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.R2), 0, 0xffffffff, 0x00020000);
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.R2), 0, (int)(unsigned)(g.M * g.ldr2 * 4), 0x00020000);
         const unsigned vo = (unsigned)((4 * lh * g.ldr2 + l31) * 4);
         const unsigned so = (unsigned)((row0 * g.ldr2 + col0) * 4);
 #pragma unroll
         for (int r = 0; r < 16; ++r)
             res[r >> 1][r & 1] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)vo, (int)(so + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldr2 * 4)), 0));
     }
-    const auto rc = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, 0xffffffff, 0x00020000);
-    const unsigned vo = (unsigned)((4 * lh * g.ldc + l31) * 4);
+    const unsigned lane_out = col0 + l31 >= g.N ? 0xfffff000u : 0u;  // past the last column: out of every descriptor's range (fits_buffer: < 2^32 - 2^20)
+    const auto rc = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)(unsigned)(g.M * g.ldc * 4), 0x00020000);
+    const unsigned vo = (unsigned)((4 * lh * g.ldc + l31) * 4) | lane_out;
     const unsigned so = (unsigned)((row0 * g.ldc + col0) * 4);
     const f32x2 bias = {cols.bias[0], cols.bias[0]}, gam = {cols.gam[0], cols.gam[0]};
 #pragma unroll
@@ -113,8 +116,11 @@ __device__ __forceinline__ void gemm_epilogue_buf(const GemmDesc &g, f32x16 &acc
 // per fragment read for the stage toggle.  Now: the DMA goes through buffer descriptors (per-lane 32-bit byte offset computed once per tile, the
 // k advance in the SCALAR offset), the wave index is made scalar once, and the loop is unrolled by two so that the LDS stage is a
 // compile-time immediate of ds_read_b128.  BUF = false keeps the flat-address form for operands beyond 4 GB.
-template <int STORE, int EP, bool SPLIT, bool BUF>
-__global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g, const GemmSplit sp) {
+// BUF: 0 = flat 64-bit DMA source addresses, 1 = buffer descriptors, 2 = buffer descriptors and identity A rows (a_map.period == 0: the row map's
+// 64-bit division is not even compiled in; most launches).  __launch_bounds__(256, 4): four workgroups per CU is what LDS allows anyway, and with the
+// 128-register budget spelled out the compiler keeps the accumulators in architectural VGPRs (no v_accvgpr_write / _read, which are VALU instructions).
+template <int STORE, int EP, bool SPLIT, int BUF>
+__global__ __launch_bounds__(256, 4) void gemm_dma_kernel(const GemmDesc g, const GemmSplit sp) {
     __shared__ __attribute__((aligned(16))) float smem[2 * DSTAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);  // the same number, provably wave-uniform: M0 and LDS bases become scalar arithmetic
@@ -174,9 +180,10 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g, const G
             m = m < g.M ? m : g.M - 1;                // rows past the edge read a valid row; their results are never stored
             int n = n0 + r;
             n = n < g.N ? n : g.N - 1;
-            ga[i] = g.A + g.a_map(m) * g.lda + c * 4;
+            const long long am = BUF == 2 ? m : g.a_map(m);
+            ga[i] = g.A + am * g.lda + c * 4;
             gb[i] = g.W + (long long)n * g.ldw + c * 4;
-            va[i] = (unsigned)((g.a_map(m) * g.lda + c * 4) * 4);
+            va[i] = (unsigned)((am * g.lda + c * 4) * 4);
             vb[i] = (unsigned)(((long long)n * g.ldw + c * 4) * 4);
         }
         auto issue = [&](int kt, int st) {
@@ -208,13 +215,10 @@ __global__ __launch_bounds__(256) void gemm_dma_kernel(const GemmDesc g, const G
         if (EP != 0) cols = gemm_epilogue_prefetch<1>(g, n0, wn * 32, l31);
         f32x16 acc[1][1];
         auto epilogue = [&](long long em0, int en0) {
-            if constexpr (BUF && STORE == STORE_ROWS && EP >= 1 && EP <= 3) {
-                if (em0 + DBM <= g.M && en0 + DBN <= g.N) {  // (uniform) full tile: addresses in scalar registers
-                    gemm_epilogue_buf<EP - 1>(g, acc[0][0], cols, em0, en0, wave_s, l31, lh);
-                    return;
-                }
-            }
-            gemm_epilogue_ep<1, 1, STORE, EP>(g, acc, cols, em0, en0, wm * 32, wn * 32, l31, lh);
+            if constexpr (BUF && STORE == STORE_ROWS && EP >= 1 && EP <= 3)
+                gemm_epilogue_buf<EP - 1>(g, acc[0][0], cols, em0, en0, wave_s, l31, lh);
+            else
+                gemm_epilogue_ep<1, 1, STORE, EP>(g, acc, cols, em0, en0, wm * 32, wn * 32, l31, lh);
         };
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
@@ -341,7 +345,7 @@ int dma_slots() {
         int dev = 0, cus = 0, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess) return 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_dma_kernel<STORE, EP, true, true>, 256, 0) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, gemm_dma_kernel<STORE, EP, true, 2>, 256, 0) != hipSuccess) return 0;
         // The occupancy API answers 5 (5 x 32 KB = the whole 160 KB of LDS), the hardware places 4: the timeline of
         // scratch/ubench/gemm_trace.hip shows exactly 4 x 256 workgroups alive.  A persistent grid must match what is really
         // resident, or the surplus workgroups start only when others finish.  EDV_GEMM_SLOTS_PER_CU overrides.
@@ -416,13 +420,15 @@ int launch_dma(const GemmDesc &d, long long tiles, hipStream_t st) {
         sp.ws = d.ws + MAX_COUNTERS;
         EDV_CHECK((size_t)MAX_COUNTERS + (size_t)sp.nsplit * 2 * SLOT <= d.ws_floats && (uintptr_t)d.ws % 16 == 0,
                   "stream-K workspace too small (gemm_workspace)");
-        if (buf) hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP, true, true>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
-        else hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP, true, false>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
+        if (buf && d.a_map.period == 0) hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP, true, 2>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
+        else if (buf) hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP, true, 1>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
+        else hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP, true, 0>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
         EDV_LAUNCH_OK();
         return 0;
     }
-    if (buf) hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP, false, true>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
-    else hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP, false, false>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
+    if (buf && d.a_map.period == 0) hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP, false, 2>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
+    else if (buf) hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP, false, 1>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
+    else hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP, false, 0>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
     EDV_LAUNCH_OK();
     return 0;
 }

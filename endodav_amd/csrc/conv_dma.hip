@@ -31,7 +31,7 @@ __device__ __attribute__((aligned(256))) float g_zero_page[64];
 // not cover a tile's whole k range leaves its accumulators in a workspace slot and the last piece of a tile to arrive merges them in
 // run order and applies the epilogue.  SPLIT = false is the plain grid and compiles to the code it was before.
 template <int WGM, int EP, bool SPLIT, bool BUF>
-__global__ __launch_bounds__(256) void conv3_dma_kernel(const GemmDesc g, const GemmSplit sp) {
+__global__ __launch_bounds__(256, 4) void conv3_dma_kernel(const GemmDesc g, const GemmSplit sp) {
     constexpr int WGN = 4 / WGM;
     constexpr int BM = 32 * WGM, BN = 32 * WGN;
     constexpr int IA = BM / 32, IB = BN / 32;  // DMA instructions per wave per k-tile (8 rows x 128 B each)
@@ -92,8 +92,9 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const GemmDesc g, const 
             const int c = spos ^ ((r >> 1) & 7);  // logical 16-byte chunk that lives at this LDS position
             long long m = m0 + r;
             m = m < g.M ? m : g.M - 1;  // rows past the edge read a valid pixel; their results are never stored
-            const long long f = m / opix;
-            const int p = (int)(m - f * opix);
+            // (BUF: M < 2^30, so the pixel decode is 32-bit arithmetic -- a 64-bit division is ~95 VALU instructions per row)
+            const long long f = BUF ? (long long)((unsigned)m / (unsigned)opix) : m / opix;
+            const int p = BUF ? (int)((unsigned)m - (unsigned)f * (unsigned)opix) : (int)(m - f * opix);
             const int oy = p / g.cOW, ox = p - oy * g.cOW;
             const int iy0 = oy * g.cS - 1, ix0 = ox * g.cS - 1;
             pa[i] = g.A + ((f * g.cH + iy0) * (long long)g.cW + ix0) * g.cC + c * 4;
@@ -174,6 +175,12 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const GemmDesc g, const 
         EpiCols<1> cols;
         if (EP != 0) cols = gemm_epilogue_prefetch<1>(g, n0, wn * 32, l31);
         f32x16 acc[1][1];
+        auto epilogue = [&]() {
+            if constexpr (BUF && EP >= 1 && EP <= 3)  // addresses in scalar registers, edge rows / columns masked by the descriptor (gemm_common.hpp)
+                gemm_epilogue_buf<EP - 1>(g, acc[0][0], cols, m0 + (wave_s / WGN) * 32, n0 + (wave_s % WGN) * 32, l31, lh);
+            else
+                gemm_epilogue_ep<1, 1, STORE_ROWS, EP>(g, acc, cols, m0, n0, wm * 32, wn * 32, l31, lh);
+        };
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
 
@@ -255,11 +262,11 @@ __global__ __launch_bounds__(256) void conv3_dma_kernel(const GemmDesc g, const 
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[0][0][r] += __hip_atomic_load(qa + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
-                gemm_epilogue_ep<1, 1, STORE_ROWS, EP>(g, acc, cols, m0, n0, wm * 32, wn * 32, l31, lh);
+                epilogue();
             }
         } else {
             // (its own call site on purpose, see gemm_dma.hip)
-            gemm_epilogue_ep<1, 1, STORE_ROWS, EP>(g, acc, cols, m0, n0, wm * 32, wn * 32, l31, lh);
+            epilogue();
         }
     }
 }
@@ -301,7 +308,10 @@ int launch_conv_ep(const GemmDesc &d, long long tiles, hipStream_t st) {
     }();
     // 32-bit byte offsets must reach every tap of every pixel, with room for the "beyond the end" offset of padding lanes
     const long long frames = (d.M - 1) / ((long long)d.cOH * d.cOW) + 1;
-    const bool buf = !buf_off && frames * d.cH * d.cW * d.cC * 4 < (1ll << 31) - (1 << 20) && (long long)d.N * d.ldw * 4 < (1ll << 32) - (1 << 20);
+    // ... and (the buffer epilogue) every element of C, R1 and R2
+    const long long ld_out = std::max(std::max(d.ldc, d.R1 ? d.ldr1 : 0), d.R2 ? d.ldr2 : 0);
+    const bool buf = !buf_off && frames * d.cH * d.cW * d.cC * 4 < (1ll << 31) - (1 << 20) && (long long)d.N * d.ldw * 4 < (1ll << 32) - (1 << 20) &&
+                     d.M * ld_out * 4 < (1ll << 32) - (1 << 20);
     const int nkt = d.K / CBK;
     GemmSplit sp{0, 1, 0, 1, 0, nullptr, nullptr};
     const int slots = conv_slots<WGM, EP>();

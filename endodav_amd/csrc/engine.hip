@@ -572,6 +572,9 @@ struct Run {
     // The 1x1 out_conv is applied BEFORE the bilinear upsample: both are linear, the interpolation
     // weights sum to one, so conv1x1(up(x)) == up(conv1x1(x)) exactly in real arithmetic, at 1/4 of
     // the GEMM work.
+    // ResidualConvUnit (util/blocks.py:68-91): x + conv2(relu(conv1(relu(x)))).  The inner ReLU is applied by conv1's epilogue (its output has no
+    // other reader) instead of on conv2's A fragments: 32 v_max_f32 per k-tile less in conv2's loop, same values.  The backward's mask
+    // (t1 > 0) reads the same from relu(t1).
     int fusion(int j, const float *x, const float *skip, int h, int w, int oh, int ow, float *out) {
         const std::string p = "head.scratch.refinenet" + std::to_string(j);
         const size_t n = (size_t)F * h * w * Fe;
@@ -593,18 +596,18 @@ struct Run {
             EDV_TRY(rcu_bias(p + ".resConfUnit1.conv1", &b1));
             EDV_TRY(packedw(p + ".resConfUnit1.conv2.weight", &w2));
             EDV_TRY(rcu_bias(p + ".resConfUnit1.conv2", &b2));
-            EDV_TRY(conv3(skip, h, w, Fe, w1, b1, Fe, 1, t1a, true));
+            EDV_TRY(conv3(skip, h, w, Fe, w1, b1, Fe, 1, t1a, true, ACT_RELU));
             // s = x + rcu1(skip) = x + skip + conv2(relu(t1)): both adds ride the conv2 epilogue
             // (skip_add at util/blocks.py:90 and :146)
-            EDV_TRY(conv3(t1a, h, w, Fe, w2, b2, Fe, 1, s, true, ACT_NONE, skip, x));
+            EDV_TRY(conv3(t1a, h, w, Fe, w2, b2, Fe, 1, s, false, ACT_NONE, skip, x));
             cur = s;
         }
         EDV_TRY(packedw(p + ".resConfUnit2.conv1.weight", &w1));
         EDV_TRY(rcu_bias(p + ".resConfUnit2.conv1", &b1));
         EDV_TRY(packedw(p + ".resConfUnit2.conv2.weight", &w2));
         EDV_TRY(rcu_bias(p + ".resConfUnit2.conv2", &b2));
-        EDV_TRY(conv3(cur, h, w, Fe, w1, b1, Fe, 1, t1b, true));
-        EDV_TRY(conv3(t1b, h, w, Fe, w2, b2, Fe, 1, t2, true, ACT_NONE, cur, nullptr));
+        EDV_TRY(conv3(cur, h, w, Fe, w1, b1, Fe, 1, t1b, true, ACT_RELU));
+        EDV_TRY(conv3(t1b, h, w, Fe, w2, b2, Fe, 1, t2, false, ACT_NONE, cur, nullptr));
         const float *wo, *bo;
         EDV_TRY(param(p + ".out_conv.weight", &wo));
         EDV_TRY(param(p + ".out_conv.bias", &bo));
@@ -628,8 +631,8 @@ struct Run {
         EDV_TRY(rcu_bias(p + ".resConfUnit1.conv1", &b1));
         EDV_TRY(packedw(p + ".resConfUnit1.conv2.weight", &w2));
         EDV_TRY(rcu_bias(p + ".resConfUnit1.conv2", &b2));
-        EDV_TRY(conv3(skip, h, w, Fe, w1, b1, Fe, 1, t, true));
-        return conv3(t, h, w, Fe, w2, b2, Fe, 1, u, true, ACT_NONE, skip, nullptr);
+        EDV_TRY(conv3(skip, h, w, Fe, w1, b1, Fe, 1, t, true, ACT_RELU));
+        return conv3(t, h, w, Fe, w2, b2, Fe, 1, u, false, ACT_NONE, skip, nullptr);
     }
     // The rest of fusion block j from s = x + u:  out = up(out_conv(s + conv2(relu(conv1(relu(s)))))) (+ add)
     int fusion_tail(int j, const float *sx, int h, int w, int oh, int ow, float *out, const float *add) {
@@ -643,8 +646,8 @@ struct Run {
         EDV_TRY(rcu_bias(p + ".resConfUnit2.conv1", &b1));
         EDV_TRY(packedw(p + ".resConfUnit2.conv2.weight", &w2));
         EDV_TRY(rcu_bias(p + ".resConfUnit2.conv2", &b2));
-        EDV_TRY(conv3(sx, h, w, Fe, w1, b1, Fe, 1, t1, true));
-        EDV_TRY(conv3(t1, h, w, Fe, w2, b2, Fe, 1, t2, true, ACT_NONE, sx, nullptr));
+        EDV_TRY(conv3(sx, h, w, Fe, w1, b1, Fe, 1, t1, true, ACT_RELU));
+        EDV_TRY(conv3(t1, h, w, Fe, w2, b2, Fe, 1, t2, false, ACT_NONE, sx, nullptr));
         EDV_TRY(param(p + ".out_conv.weight", &wo));
         EDV_TRY(param(p + ".out_conv.bias", &bo));
         EDV_TRY(linear(t2, (long long)F * h * w, Fe, wo, Fe, bo, t1));

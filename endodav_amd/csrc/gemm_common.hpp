@@ -182,6 +182,57 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmDesc &g, f32x16 (&a
     }
 }
 
+// Epilogue of one wave's 32x32 block through buffer descriptors (LDS-DMA kernels, gemm_dma.hip / conv_dma.hip) (EP = 1..3: identity row maps, compile-time activation).  The general form
+// (gemm_epilogue_fast) spends ~20 VALU instructions per output register on 64-bit addresses, row-bound compares and exec masks -- a few
+// hundred per tile, and on this part every VALU instruction is matrix-pipe time (a K = 384 GEMM tile is only 192 MFMAs per wave).  Here the
+// per-lane offset (4 lh rows + column l31) is one multiply per tile and the row advance lives in the SCALAR offset of buffer_load /
+// buffer_store: the address arithmetic is SALU, the VALU work is the arithmetic the epilogue exists for (bias, activation, gamma, residual).
+// Edge tiles need no second code path: the descriptors end at row M (num_records = M x ld x 4 bytes; the hardware range-checks voffset + soffset
+// as one sum without wrap-around -- scratch/ubench/buf_range.hip -- so stores to rows past M are dropped and loads return 0), and a lane whose
+// column is past N gets a per-lane offset near 2^32, which no scalar offset brings back into range.
+template <int ACT>
+__device__ __forceinline__ void gemm_epilogue_buf(const GemmDesc &g, f32x16 &acc, const EpiCols<1> &cols, long long row0, int col0, int l31, int lh) {
+    // row0 / col0: first row / column of the wave's block -- wave-uniform (callers derive them from readfirstlane(wave)), so they live in SGPRs
+    using f32x2 = __attribute__((ext_vector_type(2))) float;
+    f32x2 res[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) res[i] = f32x2{0.f, 0.f};
+    if (g.R1) {
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.R1), 0, (int)(unsigned)(g.M * g.ldr1 * 4), 0x00020000);
+        const unsigned vo = (unsigned)((4 * lh * g.ldr1 + l31) * 4);
+        const unsigned so = (unsigned)((row0 * g.ldr1 + col0) * 4);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            res[r >> 1][r & 1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)vo, (int)(so + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldr1 * 4)), 0));
+    }
+    if (g.R2) {
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.R2), 0, (int)(unsigned)(g.M * g.ldr2 * 4), 0x00020000);
+        const unsigned vo = (unsigned)((4 * lh * g.ldr2 + l31) * 4);
+        const unsigned so = (unsigned)((row0 * g.ldr2 + col0) * 4);
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            res[r >> 1][r & 1] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)vo, (int)(so + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldr2 * 4)), 0));
+    }
+    const unsigned lane_out = col0 + l31 >= g.N ? 0xfffff000u : 0u;  // past the last column: out of every descriptor's range (fits_buffer: < 2^32 - 2^20)
+    const auto rc = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)(unsigned)(g.M * g.ldc * 4), 0x00020000);
+    const unsigned vo = (unsigned)((4 * lh * g.ldc + l31) * 4) | lane_out;
+    const unsigned so = (unsigned)((row0 * g.ldc + col0) * 4);
+    const f32x2 bias = {cols.bias[0], cols.bias[0]}, gam = {cols.gam[0], cols.gam[0]};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        f32x2 v = f32x2{acc[2 * i], acc[2 * i + 1]} + bias;
+        if (ACT == ACT_GELU) v = f32x2{gelu_erf(v[0]), gelu_erf(v[1])};
+        if (ACT == ACT_RELU) v = f32x2{fmaxf(v[0], 0.0f), fmaxf(v[1], 0.0f)};
+        v = v * gam + res[i];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int r = 2 * i + e;
+            const float ve = e ? v[1] : v[0];  // (a bit_cast applied directly to the vector element v[e] compiles to element 0 for both e)
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ve), rc, (int)vo, (int)(so + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldc * 4)), 0);
+        }
+    }
+}
+
 // EP = 5 (see epilogue_kind): rows m = mb + dr of a 32-row block cross at most one period boundary, so one division per block suffices
 template <int FM, int FN>
 __device__ __forceinline__ void gemm_epilogue_mapped(const GemmDesc &g, f32x16 (&acc)[FM][FN], const EpiCols<FN> &cols, long long m0, int n0, int wrow,

@@ -51,59 +51,6 @@ constexpr int DSTAGE = (DBM + DBN) * DBK;  // floats per stage (16 KB)
 constexpr int SLOT = SPLIT_SLOT;
 constexpr int MAX_COUNTERS = SPLIT_MAX_COUNTERS;
 
-// Epilogue of a 64x64 tile through buffer descriptors (EP = 1..3: identity row maps, compile-time activation).  The general form
-// (gemm_epilogue_fast) spends ~20 VALU instructions per output register on 64-bit addresses, row-bound compares and exec masks -- a few
-// hundred per tile, and on this part every VALU instruction is matrix-pipe time (a K = 384 tile is only 192 MFMAs per wave).  Here the
-// per-lane offset (4 lh rows + column l31) is one multiply per tile and the row advance lives in the SCALAR offset of buffer_load /
-// buffer_store: the address arithmetic is SALU, the VALU work is the arithmetic the epilogue exists for (bias, activation, gamma, residual).
-// Edge tiles need no second code path: the descriptors end at row M (num_records = M x ld x 4 bytes; the hardware range-checks voffset + soffset
-// as one sum without wrap-around -- scratch/ubench/buf_range.hip -- so stores to rows past M are dropped and loads return 0), and a lane whose
-// column is past N gets a per-lane offset near 2^32, which no scalar offset brings back into range.
-template <int ACT>
-__device__ __forceinline__ void gemm_epilogue_buf(const GemmDesc &g, f32x16 &acc, const EpiCols<1> &cols, long long m0, int n0, int wave_s, int l31, int lh) {
-    using f32x2 = __attribute__((ext_vector_type(2))) float;
-    const int wrow = (wave_s >> 1) * 32, wcol = (wave_s & 1) * 32;
-    const long long row0 = m0 + wrow;  // scalar
-    const int col0 = n0 + wcol;        // scalar
-    f32x2 res[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) res[i] = f32x2{0.f, 0.f};
-    if (g.R1) {
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.R1), 0, (int)(unsigned)(g.M * g.ldr1 * 4), 0x00020000);
-        const unsigned vo = (unsigned)((4 * lh * g.ldr1 + l31) * 4);
-        const unsigned so = (unsigned)((row0 * g.ldr1 + col0) * 4);
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            res[r >> 1][r & 1] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)vo, (int)(so + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldr1 * 4)), 0));
-    }
-    if (g.R2) {
-        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(g.R2), 0, (int)(unsigned)(g.M * g.ldr2 * 4), 0x00020000);
-        const unsigned vo = (unsigned)((4 * lh * g.ldr2 + l31) * 4);
-        const unsigned so = (unsigned)((row0 * g.ldr2 + col0) * 4);
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            res[r >> 1][r & 1] += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, (int)vo, (int)(so + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldr2 * 4)), 0));
-    }
-    const unsigned lane_out = col0 + l31 >= g.N ? 0xfffff000u : 0u;  // past the last column: out of every descriptor's range (fits_buffer: < 2^32 - 2^20)
-    const auto rc = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)(unsigned)(g.M * g.ldc * 4), 0x00020000);
-    const unsigned vo = (unsigned)((4 * lh * g.ldc + l31) * 4) | lane_out;
-    const unsigned so = (unsigned)((row0 * g.ldc + col0) * 4);
-    const f32x2 bias = {cols.bias[0], cols.bias[0]}, gam = {cols.gam[0], cols.gam[0]};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        f32x2 v = f32x2{acc[2 * i], acc[2 * i + 1]} + bias;
-        if (ACT == ACT_GELU) v = f32x2{gelu_erf(v[0]), gelu_erf(v[1])};
-        if (ACT == ACT_RELU) v = f32x2{fmaxf(v[0], 0.0f), fmaxf(v[1], 0.0f)};
-        v = v * gam + res[i];
-#pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int r = 2 * i + e;
-            const float ve = e ? v[1] : v[0];  // (a bit_cast applied directly to the vector element v[e] compiles to element 0 for both e)
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ve), rc, (int)vo, (int)(so + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldc * 4)), 0);
-        }
-    }
-}
-
 // SPLIT = false is the plain grid (one whole tile per workgroup): the split bookkeeping and the merge compile away, which
 // keeps the hot instantiation at 48 VGPRs and its code in the instruction cache (with the merge inlined the same launches ran
 // 2 % slower end to end).
@@ -216,7 +163,7 @@ __global__ __launch_bounds__(256, 4) void gemm_dma_kernel(const GemmDesc g, cons
         f32x16 acc[1][1];
         auto epilogue = [&](long long em0, int en0) {
             if constexpr (BUF && STORE == STORE_ROWS && EP >= 1 && EP <= 3)
-                gemm_epilogue_buf<EP - 1>(g, acc[0][0], cols, em0, en0, wave_s, l31, lh);
+                gemm_epilogue_buf<EP - 1>(g, acc[0][0], cols, em0 + (wave_s >> 1) * 32, en0 + (wave_s & 1) * 32, l31, lh);
             else
                 gemm_epilogue_ep<1, 1, STORE, EP>(g, acc, cols, em0, en0, wm * 32, wn * 32, l31, lh);
         };

@@ -18,7 +18,8 @@ Rank 0 prints ONE JSON line: value = total frames of all ranks / max-over-ranks 
   cpu_baseline        the oracle (PyTorch-CPU restatement, kind "port") timed on this box's host cores on a bounded
                       sample of the same workload (rank 0, N = 1 only): median of 5 clips at n = the box's cores and at n = 8.
 --train times the fine-tune step (BASELINE.json config 4 with --encoder vitb --T 16 --image 224x280): forward + the photometric
-loss (endodav_amd/losses.py, PyTorch) + HIP backward + ONE in-place all-reduce of the flat gradient buffer + AdamW.
+loss (SSIM + L1 reprojection, automask, smoothness: fused in HIP, edv_photometric_loss; --torch-loss = the same as eager PyTorch ops,
+--l1-loss = the round-1 stand-in) + HIP backward + ONE in-place all-reduce of the flat gradient buffer + AdamW + weight refresh.
 """
 from __future__ import annotations
 

@@ -3,7 +3,7 @@
 set -u
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
-O=$R/gpurun_out/${1:-r02b}
+O=$R/gpurun_out/${1:-r02u}
 mkdir -p $O
 cd $R
 run() { # name, bench args...

@@ -297,6 +297,9 @@ int dma_slots() {
         // scratch/ubench/gemm_trace.hip shows exactly 4 x 256 workgroups alive.  A persistent grid must match what is really
         // resident, or the surplus workgroups start only when others finish.  EDV_GEMM_SLOTS_PER_CU overrides.
         if (per_cu > 4) per_cu = 4;
+        // ... and 3 is what the split runs with: at 3 and at 4 persistent workgroups per CU the step takes the same time (interleaved A/B,
+        // profiles/r02_notes.txt), and 768 runs leave a quarter fewer pieces to write and re-read than 1024 (fc2 at T = 8: 32 vs 48 MB written).
+        if (per_cu > 3) per_cu = 3;
         if (const char *e = getenv("EDV_GEMM_SLOTS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
         if (getenv("EDV_DEBUG_SLOTS")) fprintf(stderr, "gemm_dma_kernel<%d,%d>: %d CUs x %d resident workgroups\n", STORE, EP, cus, per_cu);
         return cus * per_cu;

@@ -117,6 +117,28 @@ def test_gemm(lib, cuda, M, N, K, act, use_bias, use_gamma, use_res, split):
     close(Cd, ref, 3e-6, f"gemm {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("M,N,expect_buffer", [(400_030, 1600, True), (700_030, 1600, False)], ids=["2.6GB-buffer-offsets", "4.5GB-flat-addresses"])
+def test_gemm_output_beyond_two_gigabytes(lib, cuda, M, N, expect_buffer):
+    """The buffer epilogue addresses C and the residual with 32-bit byte offsets in SCALAR registers (gemm_common.hpp, gemm_epilogue_buf): an
+    output of 2.6 GB exercises offsets past 2^31, one of 4.5 GB must take the flat-address instantiation (fits_buffer).  Checked on row blocks
+    at the start, around the 2^31 / 2^32 byte marks and at the ragged end (M % 64 != 0) against an fp64 product of the same rows."""
+    K = 32
+    g = torch.Generator(device=cuda).manual_seed(7)
+    A = torch.randn(M, K, device=cuda, generator=g)
+    W = torch.randn(N, K, device=cuda, generator=g) / math.sqrt(K)
+    bias = torch.randn(N, device=cuda, generator=g) * 0.1
+    R = torch.randn(M, N, device=cuda, generator=g)
+    C = torch.full((M, N), float("nan"), device=cuda)
+    assert (M * N * 4 < 2 ** 32 - 2 ** 20) == expect_buffer and M % 64 != 0
+    _lib.check(lib.edv_gemm(A.data_ptr(), W.data_ptr(), C.data_ptr(), M, N, K, bias.data_ptr(), 0, None, R.data_ptr(), None, 0, st()), "edv_gemm")
+    marks = [0, 2 ** 31 // (N * 4) - 100, min(2 ** 32 // (N * 4), M) - 200, M - 300]
+    for r0 in marks:
+        rows = slice(r0, min(r0 + 300, M))
+        ref = A[rows].double() @ W.double().T + bias.double() + R[rows].double()
+        close(C[rows], ref.cpu(), 3e-6, f"rows {r0}..")
+    assert torch.isfinite(C).all()  # every row was written exactly where it belongs (the buffer was NaN-filled)
+
+
 @pytest.mark.parametrize("M,split", [(1370, False), (8 * 1370, True)], ids=["plain", "streamk"])
 def test_gemm_inplace_residual(lib, cuda, M, split):
     """proj / fc2 write the residual stream in place (C aliases R)."""

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EDV_ABI_VERSION 6
+#define EDV_ABI_VERSION 7 /* 7: the split-bf16 experiment entry points (edv_gemm_sb, edv_conv3x3_sb) left the library */
 
 enum edv_lora_type { EDV_LORA_NONE = 0, EDV_LORA_LORA = 1, EDV_LORA_DVLORA = 2, EDV_LORA_SSB = 3, EDV_LORA_DASH = 4 };
 

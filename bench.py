@@ -170,9 +170,16 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # Rehearsal of the N > 1 launch path on a box with ONE GPU (this pool): EDV_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and
+    # EDV_BENCH_BACKEND=gloo carries the barrier / MAX / gradient all-reduce.  The JSON line then says "rehearsal": true -- its value is not a
+    # scaling number.  The driver's multi-GPU runs set neither: one GPU per rank, RCCL.
+    backend = os.environ.get("EDV_BENCH_BACKEND", "nccl")
+    if os.environ.get("EDV_BENCH_SHARE_GPU"):
+        local = 0
+    rehearsal = backend != "nccl" or bool(os.environ.get("EDV_BENCH_SHARE_GPU"))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    parallel.init("nccl", dev)
+    parallel.init(backend, dev)
 
     kwargs = MODELS[args.encoder]
     T, (SH, SW) = args.T, args.image_hw
@@ -185,7 +192,7 @@ def main():
     x = torch.from_numpy(synth.synth_clip(Bc, T, in_hw[0], in_hw[1], seed=rank)).to(dev)  # resident in HBM before timing
 
     if args.train:
-        return train_bench(args, model, x, dev, rank, world, kwargs)
+        return train_bench(args, model, x, dev, rank, world, kwargs, rehearsal)
     events = not args.no_kernel_events
     with torch.no_grad():
         model(x)  # creates the context (profile_* need one)
@@ -193,8 +200,8 @@ def main():
             model.profile_enable([])
         # Kernel timing happens inside the timed region, in its last LIN_STEPS steps: there every dense-GEMM launch, every attention call
         # and every bandwidth-bound kernel is bracketed with a HIP event pair on its launch stream, and the encoder runs single-stream so
-        # that a bracket times the kernel alone (by default the engine overlaps two frame groups on internal streams for short
-        # clips, which is what the other steps run).  Those steps run ~10 % slower than the others (no overlap, ~300 event pairs).
+        # that a bracket times the kernel alone (one stream is the engine's default since round 2; the head's side stream is joined around
+        # every bracket).  Those steps run a few per cent slower than the others (~300 event pairs).
         lin_from = args.steps - min(LIN_STEPS, args.steps)
         out = {}
 
@@ -288,13 +295,15 @@ def main():
             line["cpu_baseline"] = cpu_baseline(kwargs, T, (SH, SW), args.cpu_threads)
         else:
             line["cpu_baseline"] = None
+        if rehearsal:
+            line["rehearsal"] = f"{world} ranks on one GPU over {backend}: launch-path check, not a scaling number"
         print(json.dumps(line), flush=True)
     if world > 1:
         parallel.barrier()
         dist.destroy_process_group()
 
 
-def train_bench(args, model, x, dev, rank, world, kwargs):
+def train_bench(args, model, x, dev, rank, world, kwargs, rehearsal=False):
     """One fine-tune step per iteration: HIP forward keeping activations, the photometric loss on the four disparity maps in PyTorch (the
     reference's losses stay PyTorch, north_star: endodav_amd/losses.py restates utils/layers.py's SSIM / back-projection / smoothness and
     the trainer's per-scale sum), HIP backward into ONE flat gradient buffer, ONE in-place all-reduce of it, AdamW.  One clip per GPU per
@@ -390,6 +399,8 @@ def train_bench(args, model, x, dev, rank, world, kwargs):
             "gradients_in_flat_buffer": model.flat_gradients(params) is not None,
             "roofline": roofline, "loss_share": loss_share, "cpu_baseline": None,
         }
+        if rehearsal:
+            line["rehearsal"] = f"{world} ranks on one GPU: launch-path check, not a scaling number"
         print(json.dumps(line), flush=True)
     if world > 1:
         parallel.barrier()

@@ -47,6 +47,8 @@ def max_over_ranks(value: float, device: Optional[torch.device] = None) -> float
     """MAX-reduction of a host scalar (the elapsed time of a timed region)."""
     if not (dist.is_initialized() and dist.get_world_size() > 1):
         return float(value)
+    if dist.get_backend() != "nccl":
+        device = None  # gloo (CPU tests, single-GPU rehearsals): a host tensor
     t = torch.tensor([value], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

@@ -73,6 +73,8 @@ SIGNATURES = {
     "edv_layernorm": (C.c_int, [_fp, _fp, _fp, _fp, _i64, _i32, _f32, _fp, _i32, _i32, C.c_void_p]),
     "edv_gemm_workspace": (C.c_size_t, []),
     "edv_gemm": (C.c_int, [_fp, _fp, _fp, _i64, _i32, _i32, _fp, _i32, _fp, _fp, _fp, C.c_size_t, C.c_void_p]),
+    "edv_pack_geglu": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i32, C.c_void_p]),
+    "edv_gemm_geglu": (C.c_int, [_fp, _fp, _fp, _fp, _i64, _i32, _i32, C.c_void_p]),
     "edv_conv3x3": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _fp, _fp, C.c_void_p]),
     "edv_conv3x3_ws": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _fp, _fp, _fp, C.c_size_t, C.c_void_p]),
     "edv_pack_conv3x3": (C.c_int, [_fp, _fp, _i32, _i32, C.c_void_p]),

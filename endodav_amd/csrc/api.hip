@@ -22,6 +22,19 @@ int edv_gemm(const float *A_dev, const float *W_dev, float *C_dev, int64_t M, in
     return gemm(g, (hipStream_t)stream);
 }
 
+int edv_pack_geglu(const float *w_dev, const float *b_dev, float *wi_dev, float *bi_dev, int32_t N, int32_t K, void *stream) {
+    return pack_geglu(w_dev, b_dev, wi_dev, bi_dev, N, K, (hipStream_t)stream);
+}
+
+int edv_gemm_geglu(const float *A_dev, const float *Wi_dev, const float *bi_dev, float *C_dev, int64_t M, int32_t N, int32_t K, void *stream) {
+    GemmDesc g;
+    g.A = A_dev; g.lda = K; g.W = Wi_dev; g.ldw = K; g.C = C_dev; g.ldc = N / 2; g.M = M; g.N = N; g.K = K;
+    g.bias = bi_dev; g.geglu = 1;
+    EDV_CHECK(A_dev && Wi_dev && bi_dev && C_dev && M > 0, "null operand");
+    EDV_CHECK(gemm_geglu_supported(g), "edv_gemm_geglu: K % 32 == 0, N % 64 == 0, output below 4 GB");
+    return gemm(g, (hipStream_t)stream);
+}
+
 static int conv3x3_impl(const float *x_dev, const float *wpacked_dev, const float *bias_dev, float *y_dev, int32_t F, int32_t H, int32_t W, int32_t Cin,
                         int32_t Cout, int32_t stride, int32_t pre_relu, int32_t post_relu, const float *R1_dev, const float *R2_dev, float *ws,
                         size_t ws_bytes, void *stream) {

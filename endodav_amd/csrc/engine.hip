@@ -386,6 +386,15 @@ struct Run {
                 }
             }
             EDV_TRY(fold_linear(tb + ".ff.net.2", cfg.temporal_lora != 0));
+            if ((8 * C) % 64 == 0 && C % 32 == 0) {  // interleaved copy of ff.net.0.proj for the fused GEGLU launch of the inference forward
+                const float *w0, *b0;
+                float *wi, *bi;
+                EDV_TRY(param(tb + ".ff.net.0.proj.weight", &w0, 2));
+                EDV_TRY(param(tb + ".ff.net.0.proj.bias", &b0));
+                EDV_TRY(pk(tb + ".ff.net.0.geglu.w", (size_t)8 * C * C, &wi));
+                EDV_TRY(pk(tb + ".ff.net.0.geglu.b", (size_t)8 * C, &bi));
+                EDV_TRY(pack_geglu(w0, b0, wi, bi, 8 * C, C, st));
+            }
         }
         c->prepared = true;
         c->train_prepared = false;  // the folded LoRA weights changed: their transposes are stale
@@ -546,12 +555,38 @@ struct Run {
         EDV_TRY(ln(hs[2], identity_map(), tb + ".ff_norm", hn, M, C, 1e-5f));
         EDV_TRY(param(tb + ".ff.net.0.proj.weight", &w));
         EDV_TRY(param(tb + ".ff.net.0.proj.bias", &b));
-        EDV_TRY(linear(hn, M, C, w, 8 * C, b, ff1));
-        {
-            HbmScope b_(c, KC_GEGLU, st, 4.0 * (double)M * 12 * C);
-            EDV_TRY(geglu(ff1, ff2, M, 4 * C, st));
+        // Inference: the projection and the GEGLU are ONE launch (EP = 6 of gemm_dma.hip on the interleaved weight made by edv_prepare): the [M, 8C]
+        // projection is never written.  Training keeps it (the GEGLU backward reads it), so it runs the two launches.  EDV_GEGLU_FUSED=0: A/B.
+        static const bool geglu_fused = [] {
+            const char *e = getenv("EDV_GEGLU_FUSED");
+            return !(e && atoi(e) == 0);
+        }();
+        bool fused = false;
+        if (!c->train && geglu_fused && c->packed.count(tb + ".ff.net.0.geglu.w")) {
+            GemmDesc g;
+            const float *wi, *bi;
+            EDV_TRY(packedw(tb + ".ff.net.0.geglu.w", &wi));
+            EDV_TRY(packedw(tb + ".ff.net.0.geglu.b", &bi));
+            g.A = hn; g.lda = C; g.W = wi; g.ldw = C; g.C = ff2; g.ldc = 4 * C; g.M = M; g.N = 8 * C; g.K = C; g.bias = bi; g.geglu = 1;
+            if (gemm_geglu_supported(g)) {
+                c->launches++;
+                if (c->prof_mask & (1u << KC_LINEAR)) {  // 2 M N K; A, W read once, the half-width output written once
+                    c->prof_flops[KC_LINEAR] += 2.0 * (double)M * (8 * C) * C;
+                    c->prof_bytes[KC_LINEAR] += 4.0 * ((double)M * C + (double)8 * C * C + (double)M * 4 * C);
+                }
+                Bracket b_(c, KC_LINEAR, st);
+                EDV_TRY(gemm_ws(g));
+                fused = true;
+            }
         }
-        c->launches++;
+        if (!fused) {
+            EDV_TRY(linear(hn, M, C, w, 8 * C, b, ff1));
+            {
+                HbmScope b_(c, KC_GEGLU, st, 4.0 * (double)M * 12 * C);
+                EDV_TRY(geglu(ff1, ff2, M, 4 * C, st));
+            }
+            c->launches++;
+        }
         EDV_TRY(lin_w(tb + ".ff.net.2", &w));
         EDV_TRY(param(tb + ".ff.net.2.bias", &b));
         EDV_TRY(linear(ff2, M, 4 * C, w, C, b, hs[3], ACT_NONE, nullptr, hs[2]));

@@ -264,6 +264,7 @@ int gemm(const GemmDesc &d, hipStream_t st) {
         const char *e = getenv("EDV_GEMM_DMA");
         return !(e && atoi(e) == 0);
     }();
+    if (d.geglu) return gemm_dma(d, st);  // the GEGLU epilogue exists in the LDS-DMA kernel only (it checks gemm_geglu_supported)
     if (dma_on && gemm_dma_supported(d) && d.N > 32) return gemm_dma(d, st);
     static const bool conv_dma_on = [] {
         const char *e = getenv("EDV_CONV_DMA");  // 0 switches the LDS-DMA convolution off (A/B runs)

@@ -105,9 +105,11 @@ __device__ __forceinline__ void gemm_epilogue_elem(const GemmDesc &g, float accv
 // share.  A workgroup timeline (scratch/ubench/gemm_trace.hip) showed 7.8 us of a 27 us workgroup life inside it.  Every
 // encoder linear and every convolution needs only: identity row maps, no P1, a compile-time activation.
 //   EP = 0: general;  EP = 1 + ACT (ACT_NONE / ACT_GELU / ACT_RELU): fast.
+//   EP = 6: GEGLU (gemm_dma.hip): the tile's columns 0..31 are values, 32..63 their gates; C gets value * gelu(gate), half as wide.
 //   EP = 5: row-mapped output (and residual) with one period >= 32 rows, no activation -- the patch-embed GEMM, whose rows go to
 //           frame f's token slots behind the class token and take the position table as a per-frame-periodic residual.
 inline int epilogue_kind(const GemmDesc &d) {
+    if (d.geglu) return 6;  // (gemm_dma.hip only; gemm_geglu_supported() is the caller's gate)
     if (d.store == STORE_ROWS && !d.P1 && !d.R2 && d.act == ACT_NONE && d.c_map.period >= 32 && d.c_map.inner == 1 &&
         (!d.R1 || (d.r1_map.period == d.c_map.period && d.r1_map.inner == 1)))
         return 5;

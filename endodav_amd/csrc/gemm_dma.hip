@@ -162,7 +162,27 @@ __global__ __launch_bounds__(256, 4) void gemm_dma_kernel(const GemmDesc g, cons
         if (EP != 0) cols = gemm_epilogue_prefetch<1>(g, n0, wn * 32, l31);
         f32x16 acc[1][1];
         auto epilogue = [&](long long em0, int en0) {
-            if constexpr (BUF && STORE == STORE_ROWS && EP >= 1 && EP <= 3)
+            if constexpr (EP == 6) {
+                // GEGLU: the wave pair (wm, 0) / (wm, 1) holds values / gates of the same 32 output columns.  The gate wave leaves gelu(gate) in LDS
+                // (both stages are idle here), the value wave multiplies and stores 32 columns of the half-width output through a buffer descriptor.
+                float *ex = smem + (wave_s >> 1) * (16 * 64);
+                if (wave_s & 1) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) ex[r * 64 + lane] = gelu_erf(acc[0][0][r] + cols.bias[0]);
+                }
+                __syncthreads();
+                if (!(wave_s & 1)) {
+                    const auto rc = __builtin_amdgcn_make_buffer_rsrc(g.C, 0, (int)(unsigned)(g.M * g.ldc * 4), 0x00020000);
+                    const unsigned vo = (unsigned)((4 * lh * g.ldc + l31) * 4);
+                    const unsigned so = (unsigned)(((em0 + (wave_s >> 1) * 32) * g.ldc + (en0 >> 1)) * 4);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = (acc[0][0][r] + cols.bias[0]) * ex[r * 64 + lane];
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, (int)vo, (int)(so + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldc * 4)), 0);
+                    }
+                }
+                __syncthreads();  // (a persistent instantiation would refill the stages next)
+            } else if constexpr (BUF && STORE == STORE_ROWS && EP >= 1 && EP <= 3)
                 gemm_epilogue_buf<EP - 1>(g, acc[0][0], cols, em0 + (wave_s >> 1) * 32, en0 + (wave_s & 1) * 32, l31, lh);
             else
                 gemm_epilogue_ep<1, 1, STORE, EP>(g, acc, cols, em0, en0, wm * 32, wn * 32, l31, lh);
@@ -383,6 +403,15 @@ int launch_dma(const GemmDesc &d, long long tiles, hipStream_t st) {
     return 0;
 }
 
+// GEGLU epilogue (EP = 6): shallow tiles (K = C of a motion module), always the plain grid, buffer descriptors only (gemm_geglu_supported)
+int launch_geglu(const GemmDesc &d, long long tiles, hipStream_t st) {
+    const GemmSplit sp{1, 1, 0, 1, 0, nullptr, nullptr};
+    if (d.a_map.period == 0) hipLaunchKernelGGL((gemm_dma_kernel<STORE_ROWS, 6, false, 2>), dim3((unsigned)tiles), dim3(256), 0, st, d, sp);
+    else hipLaunchKernelGGL((gemm_dma_kernel<STORE_ROWS, 6, false, 1>), dim3((unsigned)tiles), dim3(256), 0, st, d, sp);
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
 }  // namespace
 
 size_t gemm_workspace() {
@@ -395,6 +424,11 @@ size_t gemm_counter_bytes() { return (size_t)MAX_COUNTERS * sizeof(int); }
 
 bool gemm_dma_supported(const GemmDesc &d) {
     return d.loader == LOAD_DENSE && d.K % DBK == 0 && d.lda % 4 == 0 && d.ldw % 4 == 0 && d.M > 0 && d.N > 0;
+}
+
+bool gemm_geglu_supported(const GemmDesc &d) {
+    return gemm_dma_supported(d) && d.store == STORE_ROWS && d.N % 64 == 0 && d.ldc >= d.N / 2 && !d.R1 && !d.R2 && !d.P1 && !d.gamma && d.bias &&
+           d.c_map.period == 0 && fits_buffer(d);
 }
 
 int gemm_dma(const GemmDesc &d, hipStream_t st) {
@@ -414,6 +448,9 @@ int gemm_dma(const GemmDesc &d, hipStream_t st) {
         case 2: return launch_dma<STORE_ROWS, 2>(d, tiles, st);
         case 3: return launch_dma<STORE_ROWS, 3>(d, tiles, st);
         case 5: return launch_dma<STORE_ROWS, 5>(d, tiles, st);
+        case 6:
+            EDV_CHECK(gemm_geglu_supported(d), "GEGLU epilogue: dense A, K % 32 == 0, N % 64 == 0, bias, no residual, outputs below 4 GB");
+            return launch_geglu(d, tiles, st);
         default: return launch_dma<STORE_ROWS, 0>(d, tiles, st);
     }
 }

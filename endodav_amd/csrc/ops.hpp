@@ -44,6 +44,9 @@ struct GemmDesc {
     int loader = LOAD_DENSE;
     int cH = 0, cW = 0, cC = 0, cOH = 0, cOW = 0, cS = 1, pre_relu = 0;
     int store = STORE_ROWS;
+    // GEGLU epilogue (gemm_dma.hip, EP = 6): W and bias come interleaved in 32-row blocks -- value rows 32b..32b+31 of the Linear, then the gate rows
+    // N/2 + 32b.. of the same block (pack_geglu) -- and C [M, N/2] (ldc >= N/2) receives value * gelu(gate): GEGLU.forward, motion_module.py
+    int geglu = 0;
     int ps_s = 0, ps_C = 0, ps_h = 0, ps_w = 0;
     // stream-K split workspace (gemm_workspace() floats, 16-byte aligned, one per concurrently running GEMM; its first
     // gemm_counter_bytes() must be zero before the first launch and are left zero by every launch);
@@ -56,6 +59,8 @@ size_t gemm_workspace();  // floats; enough for any shape on the current device
 size_t gemm_counter_bytes();  // the zero-initialised arrival counters at the head of the workspace
 // LDS-DMA staged variant (gemm_dma.hip): dense A, K % 32 == 0; picked by gemm() for small/medium grids.
 bool gemm_dma_supported(const GemmDesc &d);
+bool gemm_geglu_supported(const GemmDesc &d);  // the GEGLU epilogue: dense A, K % 32 == 0, N % 64 == 0, 32-bit output offsets
+int pack_geglu(const float *w, const float *b, float *wi, float *bi, int N, int K, hipStream_t st);  // N = both halves (8C)
 int gemm_dma(const GemmDesc &d, hipStream_t st);
 // LDS-DMA implicit-GEMM 3x3 convolution (conv_dma.hip): Cin % 32 == 0, any stride the GemmDesc allows
 bool conv_dma_supported(const GemmDesc &d);

@@ -87,7 +87,27 @@ __global__ void fold_bn_kernel(float *__restrict__ w, const float *__restrict__ 
     if (i - (long long)n * K == 0) bout[n] = (b[n] - mean[n]) * s + beta[n];
 }
 
+// GEGLU weight order (gemm_dma.hip, EP = 6): output row j of the interleaved matrix is value row 32 b + i of the Linear for j = 64 b + i (i < 32) and
+// gate row N/2 + 32 b + i for j = 64 b + 32 + i; the bias likewise
+__global__ void pack_geglu_kernel(const float *__restrict__ w, const float *__restrict__ b, float *__restrict__ wi, float *__restrict__ bi, int N, int K) {
+    const long long total = (long long)N * K;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int j = (int)(idx / K), k = (int)(idx - (long long)j * K);
+        const int blk = j >> 6, i = j & 63;
+        const int src = i < 32 ? 32 * blk + i : N / 2 + 32 * blk + (i - 32);
+        wi[idx] = w[(long long)src * K + k];
+        if (k == 0) bi[j] = b[src];
+    }
+}
+
 }  // namespace
+
+int pack_geglu(const float *w, const float *b, float *wi, float *bi, int N, int K, hipStream_t st) {
+    EDV_CHECK(w && b && wi && bi && N > 0 && K > 0 && N % 64 == 0, "pack_geglu: N (both halves) must be a multiple of 64");
+    hipLaunchKernelGGL(pack_geglu_kernel, dim3(blocks_for((long long)N * K)), dim3(256), 0, st, w, b, wi, bi, N, K);
+    EDV_LAUNCH_OK();
+    return 0;
+}
 
 int pack_conv3x3(const float *w, float *out, int Cout, int Cin, hipStream_t st) {
     EDV_CHECK(w && out && Cout > 0 && Cin > 0, "bad operand");

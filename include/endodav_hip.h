@@ -149,6 +149,13 @@ int edv_gemm(const float *A_dev, const float *W_dev, float *C_dev, int64_t M, in
  * (it starts with per-tile arrival counters, which every launch leaves at zero).  workspace_dev = NULL: one workgroup per tile. */
 size_t edv_gemm_workspace(void);
 
+/* GEGLU feed-forward input projection of the motion modules (motion_module.py: GEGLU.forward = x, gate = proj(h).chunk(2, -1); x * gelu(gate)),
+ * fused: C[M, N/2] = (A W_v^T + b_v) * gelu(A W_g^T + b_g) in ONE launch -- the [M, N] projection is never written.  edv_pack_geglu interleaves the
+ * Linear's [N, K] weight and [N] bias in 32-row blocks (value rows 32b.., then their gate rows N/2 + 32b..) so that a 64-column tile holds values
+ * and gates of the same 32 outputs; edv_gemm_geglu takes the packed pair.  N = both halves (8 C), N % 64 == 0, K % 32 == 0. */
+int edv_pack_geglu(const float *w_dev, const float *b_dev, float *wi_dev, float *bi_dev, int32_t N, int32_t K, void *stream);
+int edv_gemm_geglu(const float *A_dev, const float *Wi_dev, const float *bi_dev, float *C_dev, int64_t M, int32_t N, int32_t K, void *stream);
+
 /* 3x3 convolution, padding 1, stride 1 or 2, channels-last: x [F,H,W,Cin], w packed
  * [Cout][3][3][Cin], y [F,OH,OW,Cout]; optional ReLU on the input (util/blocks.py:79-85),
  * bias, ReLU on the output and up to two residual tensors shaped like y. */

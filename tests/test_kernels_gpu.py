@@ -456,3 +456,23 @@ def test_gelu_accuracy(lib, cuda):
     aten = (torch.nn.functional.gelu(x).double() - ref).abs()
     print(f"\n[gelu] max abs error {err.max().item():.2e} (ATen fp32 {aten.max().item():.2e}); over |x| <= 3: {err[x.abs() <= 3].max().item():.2e}")
     assert err.max().item() <= 1.5e-6 and err[x.abs() <= 3].max().item() <= 5e-7
+
+
+@pytest.mark.parametrize("M,C", [(8 * 361, 384), (1000, 64), (8 * 1369, 192), (77, 32), (43808, 64)])
+def test_gemm_geglu_epilogue(lib, cuda, M, C):
+    """ff.net.0 of a motion module + GEGLU in one launch (edv_gemm_geglu on the weight interleaved by edv_pack_geglu) against
+    x, gate = F.linear(h, W, b).chunk(2, -1); x * F.gelu(gate) in fp64 (motion_module.py GEGLU.forward); ragged M, all four module widths."""
+    N, K = 8 * C, C
+    h, W, b = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K)), rnd(N, seed=3, scale=0.2)
+    y = h.double() @ W.double().T + b.double()
+    val, gate = y.chunk(2, dim=-1)
+    ref = val * F.gelu(gate)
+    hd, Wd, bd = h.to(cuda), W.to(cuda), b.to(cuda)
+    Wi, bi = torch.empty_like(Wd), torch.empty_like(bd)
+    _lib.check(lib.edv_pack_geglu(Wd.data_ptr(), bd.data_ptr(), Wi.data_ptr(), bi.data_ptr(), N, K, st()), "edv_pack_geglu")
+    # the packing is a permutation of rows: block b of 64 = value rows 32b.., then gate rows N/2 + 32b..
+    perm = torch.cat([torch.cat([torch.arange(32 * k, 32 * k + 32), N // 2 + torch.arange(32 * k, 32 * k + 32)]) for k in range(N // 64)])
+    assert torch.equal(Wi.cpu(), W[perm]) and torch.equal(bi.cpu(), b[perm])
+    out = torch.full((M, N // 2), float("nan"), device=cuda)
+    _lib.check(lib.edv_gemm_geglu(hd.data_ptr(), Wi.data_ptr(), bi.data_ptr(), out.data_ptr(), M, N, K, st()), "edv_gemm_geglu")
+    close(out, ref, 3e-6, f"geglu {M}x{N}x{K}")

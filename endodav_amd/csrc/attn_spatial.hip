@@ -360,8 +360,15 @@ __global__ __launch_bounds__(LEAN_NW * 64, 2) void attn_lean_kernel(const float 
             constexpr int ST = decltype(st_tag)::value;
             constexpr bool FIRST = decltype(first_tag)::value;
             const int k0 = t * KT;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of K(t) and V(t) has landed
-            __builtin_amdgcn_s_barrier();                      // ... everybody's has; and every wave is done with the other stage
+            // This wave's share of K(t) and V(t) has landed (vmcnt) AND its LDS reads of tile t-1 have returned (lgkmcnt): only then may the other
+            // waves refill that stage.  Without the lgkmcnt wait the compiler leaves the previous tile's last V read in flight across the barrier
+            // (its two MFMAs sink below it); alone on the GPU the read always wins the race against the next DMA, but beside another stream's kernels
+            // one wave in a few hundred launches multiplied the NEXT tile's V rows -- 32 query rows of one head off by 1e-2, found by running the
+            // two-frame-group encoder (scratch/lanes_micro.py reproduces it in 3 s; tests/test_kernels_gpu.py::test_attention_beside_other_kernels).
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();  // ... everybody's has; and every wave is done with the other stage
             if (t + 1 < kt1) {
                 issue(t + 1, ST ^ 1, 1);
                 issue(t + 1, ST ^ 1, 2);
@@ -449,7 +456,9 @@ __global__ __launch_bounds__(LEAN_NW * 64, 2) void attn_lean_kernel(const float 
             }
             if (t < kt1) tile(t, std::integral_constant<int, 1>{}, std::false_type{});
         }
-        __builtin_amdgcn_s_barrier();  // every wave has read its last V tile before the next run's first DMA refills stage 0
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();  // every wave has READ (not just issued the reads of) its last V tile before the next run's first DMA refills stage 0
 
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         float inv = 1.0f / l_tot;

@@ -476,3 +476,51 @@ def test_gemm_geglu_epilogue(lib, cuda, M, C):
     out = torch.full((M, N // 2), float("nan"), device=cuda)
     _lib.check(lib.edv_gemm_geglu(hd.data_ptr(), Wi.data_ptr(), bi.data_ptr(), out.data_ptr(), M, N, K, st()), "edv_gemm_geglu")
     close(out, ref, 3e-6, f"geglu {M}x{N}x{K}")
+
+
+def test_attention_beside_other_kernels(lib, cuda):
+    """Two chains LayerNorm -> qkv GEMM -> spatial attention -> proj GEMM (+ residual) on two streams, the way the two-frame-group encoder runs
+    them: every buffer of every round must be bit-identical to the chain run alone.  (Round 2's attention kernel left an LDS read in flight
+    across its tile barrier; alone on the GPU that never showed, beside another stream's kernels one wave in a few hundred launches read the
+    next tile's V rows.)"""
+    Fr, N, heads = 2, 1370, 6
+    D, M = heads * 64, Fr * N
+    g = torch.Generator(device=cuda).manual_seed(3)
+    r = lambda *s, scale=1.0: torch.randn(*s, device=cuda, generator=g) * scale
+    Wq, bq, Wp, bp = r(3 * D, D, scale=0.05), r(3 * D, scale=0.1), r(D, D, scale=0.05), r(D, scale=0.1)
+    lw, lb = r(D, scale=0.1) + 1, r(D, scale=0.1)
+    nb, gb = lib.edv_attn_spatial_workspace(Fr, N, heads), lib.edv_gemm_workspace()
+
+    class Lane:
+        def __init__(self):
+            self.x0 = r(M, D)
+            self.x, self.xn, self.qkv, self.att = self.x0.clone(), torch.empty(M, D, device=cuda), torch.empty(M, 3 * D, device=cuda), torch.empty(M, D, device=cuda)
+            self.ws, self.gws, self.s = torch.zeros(max(nb // 4, 4), device=cuda), torch.zeros(gb // 4, device=cuda), torch.cuda.Stream()
+
+        def run(self, blocks=2):
+            s = self.s.cuda_stream
+            with torch.cuda.stream(self.s):
+                self.x.copy_(self.x0)
+            for _ in range(blocks):
+                _lib.check(lib.edv_layernorm(self.x.data_ptr(), lw.data_ptr(), lb.data_ptr(), self.xn.data_ptr(), M, D, 1e-6, None, 0, 0, s))
+                _lib.check(lib.edv_gemm(self.xn.data_ptr(), Wq.data_ptr(), self.qkv.data_ptr(), M, 3 * D, D, bq.data_ptr(), 0, None, None, self.gws.data_ptr(), gb, s))
+                _lib.check(lib.edv_attn_spatial(self.qkv.data_ptr(), self.att.data_ptr(), Fr, N, heads, self.ws.data_ptr(), nb, None, s))
+                _lib.check(lib.edv_gemm(self.att.data_ptr(), Wp.data_ptr(), self.x.data_ptr(), M, D, D, bp.data_ptr(), 0, None, self.x.data_ptr(), self.gws.data_ptr(), gb, s))
+
+        def snap(self):
+            return [t.clone() for t in (self.qkv, self.att, self.x)]
+
+    a, b = Lane(), Lane()
+    torch.cuda.synchronize()
+    refs = []
+    for lane in (a, b):
+        lane.run()
+        torch.cuda.synchronize()
+        refs.append(lane.snap())
+    for it in range(300):
+        a.run()
+        b.run()
+        torch.cuda.synchronize()
+        for lane, ref in zip((a, b), refs):
+            for name, got, want in zip(("qkv", "attention", "x"), lane.snap(), ref):
+                assert torch.equal(got, want), f"round {it}: {name} differs from the solo run by {float((got - want).abs().max()):.3e}"

@@ -755,14 +755,15 @@ class endodav(nn.Module):
         return int(_lib.load().edv_device_bytes(C.c_void_p(nat.handle))) if nat else 0
 
     # -------------------------------------------------------------------------------------
-    def infer_video_depth(self, frames, input_size=518, device="cuda"):
+    def infer_video_depth(self, frames, input_size=518, device="cuda", shard_windows=False):
         """Sliding-window inference over a whole video (endodav.py:162-254).
 
         ``frames``: uint8 [N, H, W, 3].  Returns float32 [N, H, W].  Windows of 32 frames, step 22; the
         first 10 slots of every later window are refilled with key frames of the previous window's
         INPUT; windows are stitched by a least-squares scale/shift on the overlap and a linear
-        cross-fade over 8 frames.
+        cross-fade over 8 frames.  ``shard_windows=True`` (not in the reference): every rank of the process group calls this with the SAME
+        video and runs a share of its windows; rank 0 gets the result, the others None (``video.infer_video_depth``).
         """
         from .video import infer_video_depth as _impl
 
-        return _impl(self, frames, input_size=input_size, device=device)
+        return _impl(self, frames, input_size=input_size, device=device, shard_windows=shard_windows)

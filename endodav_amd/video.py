@@ -7,7 +7,8 @@ Differences in *where* work happens, not in what is computed:
     (if needed) bicubically resized on the GPU by ``edv_resize_bicubic`` instead of per-frame ``cv2.resize`` on the host;
   - each window's 32 disparity maps are resized to the native frame size on the GPU by
     ``edv_bilinear`` and come back in ONE device→host copy instead of 32, behind the next window's forward;
-  - the windows of one video are independent given the input frames (``window_sources``) and shard over ranks;
+  - the windows of one video are independent given the input frames (``window_sources``) and can be sharded over ranks
+    (``shard_windows=True``, opt-in);
   - the least-squares scale/shift and the cross-fade run in numpy float32 exactly as the reference's.
 
 The cv2.INTER_CUBIC pre-resize is "parity unpinned" (cv2 is absent from the build
@@ -210,11 +211,15 @@ class HipWindowRunner:
 
 
 # ---------------------------------------------------------------------------------------------
-def infer_video_depth(model, frames, input_size=518, device="cuda", runner=None):
-    """endodav.infer_video_depth (endodav.py:162-254).  With a ``torch.distributed`` process group of more than one rank the windows
-    of this ONE video are sharded round-robin over the ranks (they depend on each other through input key frames only,
-    ``window_sources``), every rank runs its share on its own GPU, rank 0 gathers the per-window maps, stitches them in window order
-    and returns the result; the other ranks return None.  No data-path collective besides that gather.
+def infer_video_depth(model, frames, input_size=518, device="cuda", runner=None, shard_windows=False, rank=None, world=None):
+    """endodav.infer_video_depth (endodav.py:162-254).  By default every window of the video runs on the calling rank, whatever process group
+    exists: that is what ``evaluate.evaluate_video`` needs, where each rank already holds a DIFFERENT clip (sharding the windows of those clips
+    over the same ranks would pair up collectives of different clips -- ADVICE round 2).
+
+    ``shard_windows=True`` (opt-in, for ONE long video that every rank calls this function with): the windows are dealt round-robin over the
+    ranks (they depend on each other through input key frames only, ``window_sources``), every rank runs its share on its own GPU, rank 0
+    gathers the per-window maps, stitches them in window order and returns the result; the other ranks return None.  ``rank`` / ``world``
+    default to the process group's.  No data-path collective besides that gather.
 
     ``runner``: anything with ``run(sources) -> [np.ndarray [32, H, W]]`` (default ``HipWindowRunner``; the gloo tests pass a stub)."""
     from . import parallel
@@ -229,7 +234,10 @@ def infer_video_depth(model, frames, input_size=518, device="cuda", runner=None)
             raise RuntimeError("infer_video_depth runs on MI355X only (device must be a CUDA/ROCm device)")
         runner = HipWindowRunner(model, np.ascontiguousarray(frames), dev)
     sources = window_sources(n)
-    rank, world = parallel.rank_world()
+    if not shard_windows:
+        return stitch_windows(runner.run(sources), n)
+    if rank is None or world is None:
+        rank, world = parallel.rank_world()
     mine = parallel.clip_shard(len(sources), rank, world)
     windows = runner.run([sources[k] for k in mine])
     shards = parallel.gather_to_rank0(windows)

@@ -151,7 +151,7 @@ def _r2_worker(rank, world, port, q):
     # (3) one long video, windows sharded over the ranks
     frames = _video_frames()
     runner = _StubRunner(frames)
-    out = video.infer_video_depth(None, frames, runner=runner)
+    out = video.infer_video_depth(None, frames, runner=runner, shard_windows=True)
     # (4) the in-place all-reduce on a flat gradient buffer whose slices are the .grad tensors
     flat = torch.arange(12, dtype=torch.float32) * (rank + 1)
     ps = [torch.nn.Parameter(torch.zeros(2, 4)), torch.nn.Parameter(torch.zeros(4))]
@@ -200,6 +200,64 @@ def test_round2_sharded_paths_equal_the_one_rank_run():
     # (4)
     assert got["n"] == 12 and torch.equal(got["flat"], torch.arange(12, dtype=torch.float32) * 1.5)
     assert torch.equal(got["g0"], (torch.arange(8, dtype=torch.float32) * 1.5).view(2, 4))  # .grad is a view: reduced in place
+
+
+class _VideoDepther:
+    """What endodav.infer_video_depth does (endodav.py:758): delegate to video.infer_video_depth -- here with the stub runner instead of the GPU one."""
+
+    def infer_video_depth(self, colors):
+        from endodav_amd import video
+
+        return video.infer_video_depth(None, colors, runner=_StubRunner(colors))
+
+
+def _nested_worker(rank, world, port, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from endodav_amd import evaluate as ev
+
+    parallel.init("gloo")
+    # clips of DIFFERENT lengths on the two ranks (40 / 70 / 25 frames -> 2 / 4 / 2 windows): a window-level collective inside the
+    # clip-sharded loop would pair up gathers of different clips (ADVICE round 2: TypeError on rank 1, 'Connection closed by peer' on rank 0)
+    res = ev.evaluate_video(_VideoDepther(), _RaggedVideos(), depth_align="scale_shift", device=None)
+    if rank == 0:
+        q.put(res)
+    else:
+        assert res is None
+    parallel.barrier()
+    dist.destroy_process_group()
+
+
+class _RaggedVideos:
+    def __init__(self):
+        from endodav_amd import evaluate as ev
+
+        self.clips = [ev.SyntheticVideos(n_clips=1, n_frames=n, height=12, width=16, seed=7 + i)[0] for i, n in enumerate((40, 70, 25))]
+
+    def __len__(self):
+        return len(self.clips)
+
+    def __getitem__(self, i):
+        return self.clips[i]
+
+
+def test_clip_sharded_evaluation_of_a_windowing_depther_equals_the_one_rank_run():
+    """evaluate_video (clips over ranks) around a depther that runs video.infer_video_depth (windows): the two sharding layers must not nest."""
+    from endodav_amd import evaluate as ev
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_nested_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    one = ev.evaluate_video(_VideoDepther(), _RaggedVideos(), depth_align="scale_shift", device=None)
+    for k in ("errors", "temporal", "aligns", "ratios"):
+        assert np.array_equal(got[k], one[k]), k
+    assert got["errors"].shape[0] == 40 + 70 + 25
 
 
 def test_window_sources_match_the_reference_windows():

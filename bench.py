@@ -3,6 +3,9 @@
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--T 8] [--encoder vits] [--train]
 
+With --gpus N > 1 and no WORLD_SIZE in the environment the script starts its N ranks itself (self_launch: a torch.distributed.run child, before
+any GPU call here); under `python -m torch.distributed.run ... bench.py --gpus N` it is one of the ranks.
+
 One "step" = one pass of the hot path (edv_forward) over one synthetic 518x518 clip of T frames that is
 already resident in HBM.  N > 1: one process per GPU (torch.distributed.run), every rank runs its own
 clip per step, no data-path collective (clips are independent: SURVEY.md §8e) — weak scaling; the only
@@ -18,7 +21,7 @@ Rank 0 prints ONE JSON line: value = total frames of all ranks / max-over-ranks 
   cpu_baseline        the oracle (PyTorch-CPU restatement, kind "port") timed on this box's host cores on a bounded
                       sample of the same workload (rank 0, N = 1 only): median of 5 clips at n = the box's cores and at n = 8.
 --train times the fine-tune step (BASELINE.json config 4 with --encoder vitb --T 16 --image 224x280): forward + the photometric
-loss (SSIM + L1 reprojection, automask, smoothness: fused in HIP, edv_photometric_loss; --torch-loss = the same as eager PyTorch ops,
+loss (SSIM + L1 reprojection on the two warped neighbours, smoothness: fused in HIP, edv_photometric_loss; --torch-loss = the same as eager PyTorch ops,
 --l1-loss = the round-1 stand-in) + HIP backward + ONE in-place all-reduce of the flat gradient buffer + AdamW + weight refresh.
 """
 from __future__ import annotations
@@ -153,8 +156,51 @@ def hbm_roofline(model, encoder, T, image_hw, clips):
                     "groupnorm = statistics + apply launches of one call"}
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start the N ranks ourselves -- one child running
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <the same arguments>`
+    (the driver's own launch line) -- BEFORE this process has touched torch or the GPU, pass rank 0's JSON line through and exit with the
+    child's status.  The reference's analogue is `--use_dp` starting its per-GPU threads itself (trainer_end_to_end_video.py:269-271,
+    scripts/train_dp.sh)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, bufsize=1)
+    for line in proc.stdout:  # stream through: the driver reads the ONE JSON line from our stdout
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    raise SystemExit(proc.wait())
+
+
+def stub_bench(args, rank, world):
+    """EDV_BENCH_STUB=1: the launch / rendezvous / timing protocol of this file with a sleep in place of the HIP step, on CPU over gloo --
+    what tests/test_bench_launch_cpu.py runs to cover `--gpus N` starting itself.  The line says "stub": it is not a measurement."""
+    import torch.distributed as dist
+
+    from endodav_amd import parallel
+
+    parallel.init(os.environ.get("EDV_BENCH_BACKEND", "gloo"), None)
+    dt, _ = parallel.timed_region(lambda i: time.sleep(0.005), args.steps, max(args.warmup, 1), None)
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "stub": True, "value": round(world * args.T * args.steps / dt, 2), "unit": "frames/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "scaling": "weak"}), flush=True)
+    if world > 1:
+        parallel.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     import torch
     import torch.distributed as dist
 
@@ -164,10 +210,9 @@ def main():
 
     rank, world, local = parallel.env_rank_world()
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N > 1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if os.environ.get("EDV_BENCH_STUB"):
+        return stub_bench(args, rank, world)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     # Rehearsal of the N > 1 launch path on a box with ONE GPU (this pool): EDV_BENCH_SHARE_GPU=1 puts every rank on cuda:0 and

@@ -546,15 +546,15 @@ struct AttnPlan {
 };
 
 int pipe_slots() {
-    static const int slots = [] {
+    static DeviceSlotCache cache;
+    return cache.get([] {
         int dev = 0, cus = 0, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess) return 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, attn_lean_kernel, 256, 0) != hipSuccess) return 0;
         if (getenv("EDV_DEBUG_SLOTS")) fprintf(stderr, "attn_lean_kernel: %d CUs x %d resident workgroups\n", cus, per_cu);
         return cus * per_cu;
-    }();
-    return slots;
+    });
 }
 bool use_pipe() {
     static const bool on = [] {
@@ -566,14 +566,14 @@ bool use_pipe() {
 
 template <int NW, int KT>
 int resident_slots() {
-    static const int slots = [] {
+    static DeviceSlotCache cache;
+    return cache.get([] {
         int dev = 0, cus = 0, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess) return 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, attn_spatial_kernel<NW, KT>, NW * 64, 0) != hipSuccess) return 0;
         return cus * per_cu;
-    }();
-    return slots;
+    });
 }
 
 int make_plan(int F, int N, int heads, AttnPlan *p) {

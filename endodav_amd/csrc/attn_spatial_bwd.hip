@@ -312,14 +312,14 @@ struct BwdPlan {
 
 template <int MODE, int NW>
 int bwd_slots() {
-    static const int slots = [] {
+    static DeviceSlotCache cache;
+    return cache.get([] {
         int dev = 0, cus = 0, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess) return 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
         if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, attn_spatial_bwd_kernel<MODE, NW>, NW * 64, 0) != hipSuccess) return 0;
         return cus * per_cu;
-    }();
-    return slots;
+    });
 }
 
 BwdPlan make_bwd_plan(long long ntasks, int N, int slots, int rb, int oc, bool plain) {

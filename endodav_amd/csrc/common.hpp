@@ -1,6 +1,7 @@
 // Shared device/host helpers for libendodav_hip (gfx950 only; wave = 64 lanes).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdint>
 #include <cstdio>
 #include <string>
@@ -38,6 +39,25 @@ const char *get_error();
 #define EDV_LAUNCH_OK() EDV_HIP(hipGetLastError())
 
 constexpr int WAVE = 64;
+
+// Launch geometry that depends on the DEVICE (resident workgroups of a persistent kernel = CUs x occupancy) is cached per HIP device, not per
+// process: nn.DataParallel drives several devices from one process, and a partitioned or mixed node may give them different CU counts.
+// `query` runs on the current device; 0 = the query failed (not cached).
+constexpr int EDV_MAX_DEVICES = 64;
+struct DeviceSlotCache {
+    std::atomic<int> v[EDV_MAX_DEVICES];  // static storage: zero-initialised
+    template <class Q>
+    int get(Q query) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= EDV_MAX_DEVICES) return query();
+        int s = v[dev].load(std::memory_order_relaxed);
+        if (s == 0) {
+            s = query();
+            v[dev].store(s, std::memory_order_relaxed);
+        }
+        return s;
+    }
+};
 
 // Row remap: logical row m of a [frames * period] matrix lives at physical row
 //   (m / period) * stride + offset + inner * (m % period).

@@ -292,8 +292,8 @@ int conv_slots_query() {
 }
 template <int WGM, int EP>
 int conv_slots() {
-    static const int slots = conv_slots_query<WGM, EP>();
-    return slots;
+    static DeviceSlotCache cache;
+    return cache.get([] { return conv_slots_query<WGM, EP>(); });
 }
 
 template <int WGM, int EP>

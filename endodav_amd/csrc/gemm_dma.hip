@@ -308,7 +308,8 @@ inline bool fits_buffer(const GemmDesc &d) {
 
 template <int STORE, int EP>
 int dma_slots() {
-    static const int slots = [] {
+    static DeviceSlotCache cache;
+    return cache.get([] {
         int dev = 0, cus = 0, per_cu = 0;
         if (hipGetDevice(&dev) != hipSuccess) return 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
@@ -323,8 +324,7 @@ int dma_slots() {
         if (const char *e = getenv("EDV_GEMM_SLOTS_PER_CU")) per_cu = atoi(e) > 0 ? atoi(e) : per_cu;
         if (getenv("EDV_DEBUG_SLOTS")) fprintf(stderr, "gemm_dma_kernel<%d,%d>: %d CUs x %d resident workgroups\n", STORE, EP, cus, per_cu);
         return cus * per_cu;
-    }();
-    return slots;
+    });
 }
 
 template <int STORE, int EP>

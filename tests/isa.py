@@ -1,0 +1,133 @@
+"""Disassembly helpers for the ISA-level tests (CPU only: llvm-objdump on the gfx950 code objects inside the built library).
+
+The rule these tests enforce was written down in round 2 after a race that 419 green GPU tests could not see: a raw
+``s_barrier`` that releases an LDS stage must be preceded by waits on BOTH counters -- ``vmcnt(0)`` (this wave's LDS-DMAs have landed) and
+``lgkmcnt(0)`` (this wave's own LDS reads have returned) -- because after the barrier other waves refill the stage."""
+from __future__ import annotations
+
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "endodav_amd", "lib", "libendodav_hip.so")
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+
+
+@dataclass
+class Inst:
+    addr: int
+    op: str
+    args: str
+
+
+_LINE = re.compile(r"^\s+(\S+)\s*(.*?)\s*//\s*([0-9A-Fa-f]+):")
+_FUNC = re.compile(r"^[0-9a-f]+ <(.+)>:$")
+
+
+def disassemble(lib: str = LIB) -> Dict[str, List[Inst]]:
+    """{mangled kernel name: instructions} over every gfx950 bundle of the library."""
+    if not os.path.exists(OBJDUMP):
+        raise FileNotFoundError(OBJDUMP)
+    out: Dict[str, List[Inst]] = {}
+    tmp = tempfile.mkdtemp(prefix="edv_isa_")
+    try:
+        local = os.path.join(tmp, "lib.so")
+        shutil.copy(lib, local)
+        subprocess.run([OBJDUMP, "--offloading", local], check=True, capture_output=True, cwd=tmp)
+        for f in sorted(os.listdir(tmp)):
+            if "gfx950" not in f:
+                continue
+            text = subprocess.run([OBJDUMP, "-d", os.path.join(tmp, f)], check=True, capture_output=True, text=True).stdout
+            cur: Optional[List[Inst]] = None
+            for line in text.splitlines():
+                m = _FUNC.match(line)
+                if m:
+                    cur = out.setdefault(m.group(1), [])
+                    continue
+                m = _LINE.match(line)
+                if m and cur is not None:
+                    cur.append(Inst(int(m.group(3), 16), m.group(1), m.group(2)))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out
+
+
+def branch_target(i: Inst) -> Optional[int]:
+    if not (i.op.startswith("s_cbranch") or i.op == "s_branch"):
+        return None
+    simm = int(i.args.split()[0])
+    if simm >= 32768:
+        simm -= 65536
+    return i.addr + 4 + 4 * simm
+
+
+def loop_ranges(insts: List[Inst]):
+    """[lo, hi] address ranges of backward branches (loops)."""
+    r = []
+    for i in insts:
+        t = branch_target(i)
+        if t is not None and t <= i.addr:
+            r.append((t, i.addr))
+    return r
+
+
+def is_lds_access(i: Inst) -> bool:
+    return i.op.startswith("ds_")
+
+
+def is_vmem(i: Inst) -> bool:
+    return i.op.startswith(("buffer_", "global_", "flat_", "scratch_"))
+
+
+def is_lds_dma(i: Inst) -> bool:
+    return is_vmem(i) and (re.search(r"\blds\b", i.args) is not None or "_lds_" in i.op)
+
+
+def waits(i: Inst):
+    """(vmcnt, lgkmcnt) an s_waitcnt enforces; None = not constrained by this instruction."""
+    if i.op != "s_waitcnt":
+        return None, None
+    v = re.search(r"vmcnt\((\d+)\)", i.args)
+    l = re.search(r"lgkmcnt\((\d+)\)", i.args)
+    return (int(v.group(1)) if v else None), (int(l.group(1)) if l else None)
+
+
+def barrier_violations(insts: List[Inst], loops_only: bool = True) -> List[str]:
+    """Every s_barrier (inside a loop when `loops_only`) must find, scanning backwards to the previous barrier, an `s_waitcnt vmcnt(0)` with no
+    vector-memory instruction after it and an `s_waitcnt lgkmcnt(0)` with no LDS instruction after it.  A stretch between two barriers that
+    issues no LDS-DMA needs no vmcnt wait, one that issues no LDS access needs no lgkmcnt wait.  The scan is linear in address order: the
+    compiler keeps the k-loop bodies of these kernels straight-line."""
+    loops = loop_ranges(insts)
+    bad = []
+    for n, i in enumerate(insts):
+        if i.op != "s_barrier":
+            continue
+        if loops_only and not any(lo <= i.addr <= hi for lo, hi in loops):
+            continue
+        need_v = need_l = True   # still looking for the wait
+        dirty_v = dirty_l = False  # an un-waited access seen (scanning backwards) before the wait
+        for j in range(n - 1, -1, -1):
+            p = insts[j]
+            if p.op == "s_barrier":
+                break
+            v, l = waits(p)
+            if need_v and v == 0:
+                need_v = False
+            if need_l and l == 0:
+                need_l = False
+            if need_v and is_lds_dma(p):
+                dirty_v = True
+            if need_l and is_lds_access(p):
+                dirty_l = True
+            if not need_v and not need_l:
+                break
+        if dirty_v:
+            bad.append(f"{i.addr:#x}: LDS-DMA in flight across s_barrier (no s_waitcnt vmcnt(0) after it)")
+        if dirty_l:
+            bad.append(f"{i.addr:#x}: LDS access in flight across s_barrier (no s_waitcnt lgkmcnt(0) after it)")
+    return bad

@@ -602,6 +602,8 @@ int make_plan(int F, int N, int heads, AttnPlan *p) {
     EDV_CHECK(slots > 0, "occupancy query failed");
     const long long ntasks = (long long)F * heads * ((N + nw * 32 - 1) / (nw * 32));
     EDV_CHECK(ntasks < (1ll << 31), "grid limits");
+    // the lean kernel addresses one frame's q|k|v rows through a buffer descriptor with 32-bit byte offsets (N x 3 x heads x 64 floats per frame)
+    EDV_CHECK(!p->pipe || (long long)(N + 64) * heads * 3 * HD * 4 < (1ll << 31), "one frame's q|k|v rows exceed the 2 GB a buffer descriptor offset reaches");
     p->ntasks = (int)ntasks;
     p->ntiles = (N + p->kt - 1) / p->kt;
     if (plain) {

@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256, 4) void conv3_dma_kernel(const GemmDesc g, con
                 const int arrived = __hip_atomic_fetch_add(&sp.cnt[lt], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int last = arrived == g1 - g0;
                 if (last) __hip_atomic_store(&sp.cnt[lt], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (last) split_merge_acquire();  // this CU's L1 may hold stale lines of the piece slots (gemm_common.hpp)
                 *s_last = last;
             }
             __syncthreads();
@@ -311,7 +312,7 @@ int launch_conv_ep(const GemmDesc &d, long long tiles, hipStream_t st) {
     // ... and (the buffer epilogue) every element of C, R1 and R2
     const long long ld_out = std::max(std::max(d.ldc, d.R1 ? d.ldr1 : 0), d.R2 ? d.ldr2 : 0);
     const bool buf = !buf_off && frames * d.cH * d.cW * d.cC * 4 < (1ll << 31) - (1 << 20) && (long long)d.N * d.ldw * 4 < (1ll << 32) - (1 << 20) &&
-                     d.M * ld_out * 4 < (1ll << 32) - (1 << 20);
+                     (d.M + 64) * ld_out * 4 < (1ll << 32) - 4096;  // rows up to 63 past M must not wrap the 32-bit scalar offsets (gemm_dma.hip, fits_buffer)
     const int nkt = d.K / CBK;
     GemmSplit sp{0, 1, 0, 1, 0, nullptr, nullptr};
     const int slots = conv_slots<WGM, EP>();

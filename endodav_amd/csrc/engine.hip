@@ -2110,24 +2110,52 @@ int edv_grad_bind_flat(edv_ctx *ctx, int32_t n, const char *const *names, const 
     if (!flat_dev) return 0;  // layout query
     EDV_CHECK(flat_floats >= off && (uintptr_t)flat_dev % 16 == 0, "flat gradient buffer too small or not 16-byte aligned");
     ctx->flat.clear();
-    for (int i = 0; i < n; ++i) ctx->flat[names[i]] = edv_ctx::FlatSlot{flat_dev + offsets_out[i], (size_t)numels[i], false};
+    for (int i = 0; i < n; ++i) {
+        ctx->flat[names[i]] = edv_ctx::FlatSlot{flat_dev + offsets_out[i], (size_t)numels[i], false};
+        // an owned buffer of an earlier unbound backward would otherwise keep answering edv_grad with a stale gradient once the name is unbound again
+        auto old = ctx->grads.find(names[i]);
+        if (old != ctx->grads.end()) {
+            if (old->second.p) {
+                ctx->bytes -= old->second.cap * sizeof(float);
+                (void)hipFree(old->second.p);
+            }
+            ctx->grads.erase(old);
+        }
+    }
+    return 0;
+}
+
+// Where the latest backward left the gradient of `name`: its slice of the caller's flat buffer when the name is bound (edv_grad_bind_flat), the
+// context-owned buffer otherwise.  A bound name never falls through to an owned buffer of an earlier, unbound backward (binding erases those).
+static int find_grad(edv_ctx *ctx, const char *name, float **p, size_t *n) {
+    auto f = ctx->flat.find(name);
+    if (f != ctx->flat.end()) {
+        EDV_CHECK(f->second.written, std::string("no gradient for ") + name + " yet: it is bound to the flat buffer and no backward has written it");
+        *p = f->second.p;
+        *n = f->second.numel;
+        return 0;
+    }
+    auto it = ctx->grads.find(name);
+    EDV_CHECK(it != ctx->grads.end() && it->second.p, std::string("no gradient for ") + name);
+    *p = it->second.p;
+    *n = it->second.cap;
     return 0;
 }
 
 int edv_grad_copy(edv_ctx *ctx, const char *name, float *dst_dev, int64_t numel, void *stream) {
     EDV_CHECK(ctx && name && dst_dev, "null argument");
-    auto it = ctx->grads.find(name);
-    EDV_CHECK(it != ctx->grads.end() && it->second.p, std::string("no gradient for ") + name);
-    EDV_CHECK(numel > 0 && (size_t)numel <= it->second.cap, std::string("gradient size mismatch for ") + name);
-    return copy_f32(it->second.p, dst_dev, numel, (hipStream_t)stream);
+    float *p;
+    size_t n;
+    EDV_TRY(find_grad(ctx, name, &p, &n));
+    EDV_CHECK(numel > 0 && (size_t)numel <= n, std::string("gradient size mismatch for ") + name);
+    return copy_f32(p, dst_dev, numel, (hipStream_t)stream);
 }
 
 int edv_grad(edv_ctx *ctx, const char *name, float **grad_dev, int64_t *numel) {
     EDV_CHECK(ctx && name && grad_dev && numel, "null argument");
-    auto it = ctx->grads.find(name);
-    EDV_CHECK(it != ctx->grads.end() && it->second.p, std::string("no gradient for ") + name);
-    *grad_dev = it->second.p;
-    *numel = (int64_t)it->second.cap;
+    size_t n;
+    EDV_TRY(find_grad(ctx, name, grad_dev, &n));
+    *numel = (int64_t)n;
     return 0;
 }
 

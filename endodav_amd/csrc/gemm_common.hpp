@@ -21,6 +21,21 @@ struct GemmSplit {
     float *ws;   // piece slots (after the counters)
     int *cnt;    // one arrival counter per split tile
 };
+// The merging workgroup's acquire (round 3).  The piece exchange stores and loads every piece word sc1 behind a drained, barrier-ordered counter add:
+// the form MI355X_MICROARCH.md ("Valid forms") measures as sufficient WITHOUT an acquire -- but only at one workgroup per CU, and the split launches
+// run three.  Outside that table the guide says "keep the acquire", so the ONE lane whose counter add completes a tile invalidates its CU's L1
+// (buffer_inv sc1) and waits for it before the workgroup barrier that precedes the piece loads: poll -> acquire -> vmcnt(0) -> barrier -> loads, the
+// guide's consumer sequence.  Only the last arriver of a split tile pays it (priced at 1.7-7 us by the guide; measured on the step in
+// profiles/r03_notes.txt).  -DEDV_SPLIT_ACQUIRE=0 builds the round-2 form for A/B runs.
+#ifndef EDV_SPLIT_ACQUIRE
+#define EDV_SPLIT_ACQUIRE 1
+#endif
+__device__ __forceinline__ void split_merge_acquire() {
+#if EDV_SPLIT_ACQUIRE
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
 constexpr int SPLIT_SLOT = 64 * 64;        // floats per piece: a 64x64 or 128x32 tile in accumulator order, (wave * 16 + r) * 64 + lane
 constexpr int SPLIT_MAX_COUNTERS = 4096;   // >= the tiles a launch may split
 

@@ -242,7 +242,9 @@ __global__ __launch_bounds__(256, 4) void gemm_dma_kernel(const GemmDesc g, cons
             //             CU's L1), in run order whatever the arrival order was.
             // This is the "sc1 stores + drained counter + sc1 loads" hand-off the CDNA4 guide measures as valid (MI355X_MICROARCH.md,
             // Workgroup dispatch ..., Valid forms: one lane signals for all of its workgroup's stores after every wave's vmcnt(0) and
-            // the barrier; every load of the handed-off bytes is an sc1 load issued after the add has returned and a barrier).  It is
+            // the barrier; every load of the handed-off bytes is an sc1 load issued after the add has returned and a barrier) -- measured
+            // there at ONE workgroup per CU; this launch runs three, so the merging workgroup also executes the agent-scope acquire the
+            // guide prescribes outside its table (split_merge_acquire, gemm_common.hpp).  It is
             // an ISA-level contract of gfx950 / ROCm 7.2, NOT a guarantee of the C++ memory model: the __syncthreads() between the
             // counter add and the loads is what keeps the compiler from hoisting the loads (a workgroup-scope fence), the hardware
             // ordering comes from sc1.  tests/test_streamk_fuzz_gpu.py::test_piece_exchange_contract_under_uneven_load is the gate to
@@ -259,6 +261,7 @@ __global__ __launch_bounds__(256, 4) void gemm_dma_kernel(const GemmDesc g, cons
                 const int arrived = __hip_atomic_fetch_add(&sp.cnt[lt], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const int last = arrived == g1 - g0;
                 if (last) __hip_atomic_store(&sp.cnt[lt], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // all pieces in: zero for the next launch
+                if (last) split_merge_acquire();  // this CU's L1 may hold stale lines of the piece slots (gemm_common.hpp)
                 *s_last = last;
             }
             __syncthreads();
@@ -301,9 +304,12 @@ __global__ __launch_bounds__(256, 4) void gemm_dma_kernel(const GemmDesc g, cons
 inline bool fits_buffer(const GemmDesc &d) {
     const long long a_rows = d.a_map(d.M - 1) + 1, lim = (1ll << 32) - (1 << 20);
     if (!(a_rows * d.lda * 4 < lim && (long long)d.N * d.ldw * 4 < lim)) return false;
-    // the buffer epilogue (identity row maps only: EP 1..3) addresses C, R1 and R2 with 32-bit byte offsets as well
+    // The buffer epilogue (identity row maps only: EP 1..3) addresses C, R1 and R2 with 32-bit byte offsets as well, and it masks ragged edges
+    // through the descriptor alone: a tile's rows run up to 63 past M, and their scalar offsets ((row0 + dr) * ld + col0) * 4 are computed in 32
+    // bits -- they must not wrap, or a row past the end would come back INTO range and be stored.  Lanes past column N carry 0xfffff000, which
+    // must lie at or beyond num_records = M * ld * 4.  Both hold iff (M + 64) rows of the widest operand stay below 2^32 - 4096 bytes.
     const long long ld = std::max(std::max(d.ldc, d.R1 ? d.ldr1 : 0), d.R2 ? d.ldr2 : 0);
-    return (long long)d.M * ld * 4 < lim;
+    return (long long)(d.M + 64) * ld * 4 < (1ll << 32) - 4096;
 }
 
 template <int STORE, int EP>

@@ -480,6 +480,19 @@ def test_gradients_live_in_one_flat_buffer(lib, cuda):
     before = flat.clone()
     assert parallel.allreduce_gradients(params, model=model) == sum(p.numel() for p in params)  # world 1: in place, nothing to do
     assert torch.equal(flat, before)
+    # the C API's per-tensor accessors answer from the flat slices for bound names (they used to look only at the context-owned
+    # buffers and returned "no gradient", or a stale one of an earlier unbound backward)
+    import ctypes as C
+
+    h = C.c_void_p(model._last.handle)
+    for i, n in enumerate(fg.names):
+        ptr, numel = C.c_void_p(), C.c_int64()
+        assert lib.edv_grad(h, n.encode(), C.byref(ptr), C.byref(numel)) == 0, lib.edv_last_error()
+        assert ptr.value == flat.data_ptr() + 4 * fg.offsets[i] and numel.value == sd[n].numel(), n
+        got = torch.empty(sd[n].numel(), device=cuda)
+        assert lib.edv_grad_copy(h, n.encode(), got.data_ptr(), got.numel(), None) == 0, lib.edv_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(got, sd[n].grad.reshape(-1)), n
     # a parameter set that is not the buffer's: the packed fallback is taken (None here)
     assert model.flat_gradients(params[:-1]) is None
 

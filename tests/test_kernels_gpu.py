@@ -226,6 +226,89 @@ def test_conv3x3(lib, cuda, Fr, H, W, Cin, Cout, stride, pre, post, res, split):
     close(y.permute(0, 3, 1, 2), ref, 3e-6, "conv3x3")
 
 
+# ---- guard bands: the buffer epilogue masks ragged edges ONLY through descriptor range checks (rows >= M dropped because
+# voffset + soffset is checked as one non-wrapping sum, columns >= N through a per-lane offset near 2^32).  Here C, R1 and R2 are slices of
+# larger sentinel-filled allocations: a store that escapes the descriptor lands in a guard and is seen.
+GUARD = 64 * 1024  # floats on either side: more than 63 rows x ld of every case below
+
+
+def _guarded(t, cuda, fill):
+    big = torch.full((t.numel() + 2 * GUARD,), fill, device=cuda)
+    big[GUARD:GUARD + t.numel()] = t.reshape(-1).to(cuda)
+    return big, big[GUARD:GUARD + t.numel()].view(t.shape)
+
+
+def _guards_intact(big, n, fill):
+    return bool((big[:GUARD] == fill).all()) and bool((big[GUARD + n:] == fill).all())
+
+
+@pytest.mark.parametrize("M,N,K,act,use_gamma,use_res", [
+    (64 * 5 + 1, 384 - 7, 384, 0, True, True),     # one row and 25 columns into the last tiles
+    (64 * 40 + 63, 32 * 9 + 1, 96, 1, False, False),
+    (1370, 48, 384, 0, False, True),
+    (8 * 1370 + 13, 384 - 31, 1536, 0, True, True),  # stream-K: the merged epilogue of a ragged tile
+])
+@pytest.mark.parametrize("split", [False, True], ids=["plain", "streamk"])
+def test_gemm_ragged_edges_stay_inside_guard_bands(lib, cuda, M, N, K, act, use_gamma, use_res, split):
+    A, W = rnd(M, K, seed=1), rnd(N, K, seed=2, scale=1 / math.sqrt(K))
+    bias, gamma = rnd(N, seed=3, scale=0.1), (rnd(N, seed=4) + 1.2 if use_gamma else None)
+    R = rnd(M, N, seed=5) if use_res else None
+    ref = A.double() @ W.double().T + bias.double()
+    if act == 1:
+        ref = F.gelu(ref)
+    if gamma is not None:
+        ref = ref * gamma.double()
+    if R is not None:
+        ref = ref + R.double()
+    SENT = 12345.0
+    bigC, Cd = _guarded(torch.full((M, N), float("nan")), cuda, SENT)
+    bigR, Rd = _guarded(R, cuda, float("nan")) if R is not None else (None, None)  # a read past the residual's end would put a NaN into C
+    ws, nbytes = gemm_ws(lib, cuda) if split else (None, 0)
+    g = None if gamma is None else gamma.to(cuda)
+    _lib.check(lib.edv_gemm(A.to(cuda).data_ptr(), W.to(cuda).data_ptr(), Cd.data_ptr(), M, N, K, bias.to(cuda).data_ptr(), act, _lib.ptr(g), _lib.ptr(Rd),
+                            _lib.ptr(ws), nbytes, st()), "edv_gemm")
+    torch.cuda.synchronize()
+    assert _guards_intact(bigC, M * N, SENT), "a store escaped the C descriptor"
+    close(Cd, ref, 3e-6, f"gemm {M}x{N}x{K} in guard bands")
+
+
+@pytest.mark.parametrize("Fr,H,W,Cin,Cout,stride,res", [
+    (1, 9, 7, 32, 48, 1, 2),     # 63 pixels: one ragged 64-row tile; Cout not a multiple of 64
+    (3, 13, 11, 64, 96, 1, 1),   # 429 pixels
+    (2, 37, 37, 64, 64, 2, 0),   # stride 2: 19 x 19 outputs
+    (8, 19, 19, 384, 64, 1, 2),  # split along K with a workspace
+])
+@pytest.mark.parametrize("split", [False, True], ids=["plain", "streamk"])
+def test_conv3x3_ragged_edges_stay_inside_guard_bands(lib, cuda, Fr, H, W, Cin, Cout, stride, res, split):
+    x = rnd(Fr, Cin, H, W, seed=1)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=1 / math.sqrt(9 * Cin))
+    b = rnd(Cout, seed=3, scale=0.1)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=1)
+    OH, OW = ref.shape[-2:]
+    Rs = [rnd(Fr, Cout, OH, OW, seed=4 + i) for i in range(res)]
+    for r in Rs:
+        ref = ref + r.double()
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous()
+    SENT = -4321.0
+    bigY, y = _guarded(torch.full((Fr, OH, OW, Cout), float("nan")), cuda, SENT)
+    # the input sits in guard bands of NaN as well: a padding tap that read real memory instead of zeros would poison the border outputs
+    bigX, xd = _guarded(nhwc(x), cuda, float("nan"))
+    rd = [_guarded(nhwc(r), cuda, float("nan"))[1] for r in Rs] + [None, None]
+    wd, bd = w.to(cuda), b.to(cuda)
+    wp = torch.empty(Cout * 9 * Cin, device=cuda)
+    _lib.check(lib.edv_pack_conv3x3(wd.data_ptr(), wp.data_ptr(), Cout, Cin, st()))
+    if split:
+        ws, nbytes = gemm_ws(lib, cuda)
+        _lib.check(lib.edv_conv3x3_ws(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), y.data_ptr(), Fr, H, W, Cin, Cout, stride, 0, 0, _lib.ptr(rd[0]), _lib.ptr(rd[1]),
+                                      ws.data_ptr(), nbytes, st()), "edv_conv3x3_ws")
+    else:
+        _lib.check(lib.edv_conv3x3(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), y.data_ptr(), Fr, H, W, Cin, Cout, stride, 0, 0, _lib.ptr(rd[0]), _lib.ptr(rd[1]), st()),
+                   "edv_conv3x3")
+    torch.cuda.synchronize()
+    assert _guards_intact(bigY, y.numel(), SENT), "a store escaped the output descriptor"
+    close(y.permute(0, 3, 1, 2), ref, 3e-6, "conv3x3 in guard bands")
+
+
 @pytest.mark.parametrize("Fr,h,w,Cc,s", [(2, 37, 37, 48, 4), (2, 16, 20, 96, 2), (1, 3, 4, 32, 4)])
 def test_conv_transpose(lib, cuda, Fr, h, w, Cc, s):
     x, wt, b = rnd(Fr, Cc, h, w, seed=1), rnd(Cc, Cc, s, s, seed=2, scale=1 / math.sqrt(Cc)), rnd(Cc, seed=3, scale=0.1)

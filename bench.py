@@ -63,6 +63,8 @@ def parse():
                     "their convolutions are trainable next to the LoRA factors, endodav/layers.py:5-34)")
     ap.add_argument("--lora", default="dvlora", choices=["none", "lora", "dvlora", "ssb"], help="lora_type (the reference's train_video*.sh use ssb)")
     ap.add_argument("--temporal-lora", action="store_true", help="LoRA on ff.net.2 of the motion modules too (--temporal_lora)")
+    ap.add_argument("--in-flight", type=int, default=0, help="clips in flight on the GPU (pipeline.ClipsInFlight): 0 = auto_depth (3 at the headline shape, "
+                    "1 for clips that fill the part alone), 1 = one clip at a time")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(16, cores): the box's CPU share)")
@@ -206,7 +208,7 @@ def main():
 
     import endodav_amd
     from endodav_amd import parallel, synth
-    from endodav_amd.pipeline import ClipPipeline
+    from endodav_amd.pipeline import ClipPipeline, ClipsInFlight
 
     rank, world, local = parallel.env_rank_world()
     if world != args.gpus:
@@ -249,16 +251,43 @@ def main():
         # every bracket).  Those steps run a few per cent slower than the others (~300 event pairs).
         lin_from = args.steps - min(LIN_STEPS, args.steps)
         out = {}
+        # Consecutive clips are independent, so the engine keeps several in flight (pipeline.ClipsInFlight: one context + stream per lane, depth
+        # by auto_depth -- 3 at the headline shape, 1 for clips that fill the part alone).  Every step still is one whole forward of one clip,
+        # submitted back to back; the closing synchronize of the timed region waits for all of them.  The bracketed steps run one at a time
+        # (a bracket must time its kernel alone), after the clips in flight have drained.
+        depth = args.in_flight if args.in_flight > 0 else ClipsInFlight.auto_depth(model, Bc * T)
+        flight = ClipsInFlight(model, dev, depth=depth) if depth > 1 else None
+        handles = []
 
         def step(i):
             if i == lin_from and events:
+                if flight is not None:
+                    torch.cuda.synchronize(dev)
                 model.set_encoder_streams(1)
                 model.profile_set(["attn_spatial", "linear"] + list(endodav_amd._lib.HBM_CLASSES))
-            out["maps"] = model(x)
+            if flight is not None and not (events and i >= lin_from):
+                handles.append(flight.submit(x, resident=True))  # x has been in HBM since before the timed region
+                if len(handles) > depth:
+                    handles.pop(0)
+            else:
+                out["maps"] = model(x)
 
         dt, _ = parallel.timed_region(step, args.steps, max(args.warmup, 1), dev)
         if events:
             model.set_encoder_streams(-1)
+        if "maps" not in out:
+            out["maps"] = handles[-1].result()
+        serial_value = None
+        if flight is not None:  # the same steps one clip at a time (reported beside `value`, never as it)
+            n_s = max(args.steps // 2, 4)
+            if events:
+                model.profile_set([])  # no brackets in these steps (what was recorded stays)
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(n_s):
+                model(x)
+            torch.cuda.synchronize(dev)
+            serial_value = Bc * T * n_s / (time.perf_counter() - t1)
     out = out["maps"]
 
     # Dominant kernel by time (profiles/r02_*_kernel_stats.csv): gemm_dma_kernel, the dense F.linear / 1x1-conv GEMM; second: the encoder
@@ -329,10 +358,12 @@ def main():
             "config": {"workload": f"ViT-{args.encoder[-1].upper()} endodav (features {kwargs['features']}, out_channels {kwargs['out_channels']}, "
                                    f"{args.lora} r=4, {'conv head' if args.conv_head else 'VDA head'}), {Bc} synthetic {SH}x{SW} T={T} clip(s) per GPU per step "
                                    "(BASELINE.json configs[1] shape at the defaults), hash-initialised weights", "encoder": args.encoder, "T": T,
-                       "image": [SH, SW], "clips_per_gpu_per_step": Bc, "parallelism": f"clip-sharded x{world}, no data-path collective"},
+                       "image": [SH, SW], "clips_per_gpu_per_step": Bc, "clips_in_flight": depth,
+                       "parallelism": f"clip-sharded x{world}, no data-path collective; {depth} consecutive clip(s) in flight per GPU (one engine context and HIP stream each)"},
             "model_tflop_per_clip": round(GFLOP_PER_FRAME[args.encoder] * T / 1e3 * px, 4),
             "model_tflops": round(GFLOP_PER_FRAME[args.encoder] * px * value / 1e3, 2),
             "launches_per_step": model.launch_count(), "device_mem_mb": round(model.device_bytes() / 2 ** 20, 1), "output_finite": finite,
+            "one_clip_at_a_time_value": None if serial_value is None else round(serial_value, 2),
             "pcie_inclusive_value": None if pcie_value is None else round(pcie_value, 2),
             "roofline": roofline, "roofline_attention": roofline_attn, "roofline_hbm": roofline_hbm,
         }

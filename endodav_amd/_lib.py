@@ -11,7 +11,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EDV_LIB_PATH") or os.path.join(_HERE, "lib", "libendodav_hip.so")  # override: experiments only
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 LORA_TYPES = {"none": 0, "lora": 1, "dvlora": 2, "ssb": 3, "dash": 4}
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_SIGMOID_NEG = 0, 1, 2, 3, 4
@@ -113,6 +113,7 @@ SIGNATURES = {
     "edv_groupnorm": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _f32, _fp, C.c_size_t, C.c_void_p]),
     "edv_geglu": (C.c_int, [_fp, _fp, _i64, _i32, C.c_void_p]),
     "edv_rope_qk": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
+    "edv_debug_fill_lds": (C.c_int, [C.c_float, C.c_void_p]),
     "edv_bilinear": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
     "edv_dot_channels": (C.c_int, [_fp, _fp, _fp, _fp, _i64, _i32, _i32, C.c_void_p]),
     "edv_patchify": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),

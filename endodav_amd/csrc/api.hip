@@ -164,6 +164,28 @@ int edv_groupnorm(const float *x_dev, const float *w_dev, const float *b_dev, fl
     return groupnorm(x_dev, w_dev, b_dev, y_dev, stats_dev, F, P, C, groups, eps, (hipStream_t)stream, workspace_dev, workspace_bytes / sizeof(float));
 }
 
+// Test hook: every CU's whole LDS (160 KB) filled with `value` -- LDS keeps its contents between kernels, so a kernel that reads LDS bytes it never
+// wrote (or relies on the DMA writing something it does not write) sees the poison.  tests/test_kernels_gpu.py::test_attention_on_poisoned_lds.
+namespace edv {
+namespace {
+__global__ __launch_bounds__(256) void fill_lds_kernel(float value, float *sink) {
+    extern __shared__ float lds_all[];
+    for (int i = threadIdx.x; i < 160 * 256; i += 256) lds_all[i] = value;
+    __syncthreads();
+    if (sink && lds_all[(threadIdx.x * 97) % (160 * 256)] != value) *sink = 1.f;  // keeps the stores alive
+}
+}  // namespace
+}  // namespace edv
+int edv_debug_fill_lds(float value, void *stream) {
+    int dev = 0, cus = 0;
+    EDV_HIP(hipGetDevice(&dev));
+    EDV_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    EDV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edv::fill_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(edv::fill_lds_kernel, dim3((unsigned)(8 * cus)), dim3(256), 160 * 1024, (hipStream_t)stream, value, (float *)nullptr);
+    EDV_LAUNCH_OK();
+    return 0;
+}
+
 int edv_geglu(const float *x_dev, float *y_dev, int64_t M, int32_t inner, void *stream) { return geglu(x_dev, y_dev, M, inner, (hipStream_t)stream); }
 
 int edv_bilinear(const float *x_dev, float *y_dev, int32_t F, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void *stream) {

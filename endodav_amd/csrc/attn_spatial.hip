@@ -297,11 +297,10 @@ __global__ __launch_bounds__(LEAN_NW * 64, 2) void attn_lean_kernel(const float 
 #pragma unroll
     for (int qq = 0; qq < 8; ++qq) kaddr[qq] = smem + l31 * HD + (((2 * qq + lh) ^ (l31 & 15)) << 2);
     const float *vaddr = smem + 2 * TILE + 4 * lh * HD + l31;
-    // Rows past the sequence end are not written by the DMA (outside the descriptor): whatever the stage held before stays.  Their scores
-    // are masked and their probabilities are exactly 0, but 0 x NaN is NaN in the PV product -- so the stages start as zeros, not as
-    // whatever bit patterns the LDS held.
-    for (int i = tid; i < 4 * TILE; i += NW * 64) smem[i] = 0.f;
-    __syncthreads();
+    // Key / value rows past the sequence end lie beyond the descriptor's num_records: for such a lane the DMA writes ZEROS into its LDS bytes
+    // (measured: scratch/ubench/lds_dma_oob.hip, profiles/r03_notes.txt -- the same property conv_dma.hip's padding taps rely on).  Their scores are
+    // masked and their probabilities are exactly 0, and 0 x 0 keeps the PV product clean; no stage needs clearing beforehand.  (Round 2 zero-filled
+    // both stages here on the opposite assumption -- that out-of-range rows keep stale LDS contents, where 0 x NaN would poison PV.)
 
     const int task_l0 = whole_rounds * G;
     long long u = (long long)bid * chunk;

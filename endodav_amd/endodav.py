@@ -555,9 +555,12 @@ class endodav(nn.Module):
         cfg.residual_mask = mask
         return cfg
 
-    def _ensure_ctx(self, device: torch.device) -> int:
+    def _ensure_ctx(self, device: torch.device, lane: int = 0) -> int:
+        """The engine context of ``device`` (created, bound and prepared on first use; re-folded when trainable tensors changed).  ``lane`` > 0:
+        further contexts of the same device -- own workspace, same bound parameters -- for clips in flight beside each other
+        (``pipeline.ClipsInFlight``); profiling / stage taps / the training path stay on lane 0."""
         lib = _lib.load()
-        key = str(device) + ("+dash" if (self.lora_type == "dash" and self._dash_calls > DashLinear.WARMUP) else "")
+        key = str(device) + ("+dash" if (self.lora_type == "dash" and self._dash_calls > DashLinear.WARMUP) else "") + (f"#{lane}" if lane else "")
         nat = self._native.get(key)
         if nat is None:
             h = C.c_void_p()
@@ -565,7 +568,8 @@ class endodav(nn.Module):
             _lib.check(lib.edv_create(C.byref(cfg), C.byref(h)), "edv_create")
             nat = self._native[key] = _NativeCtx(h.value, device)
         lib.edv_set_capture(C.c_void_p(nat.handle), int(self._capture))
-        self._last = nat
+        if lane == 0:
+            self._last = nat
         # (re)bind + repack whenever a tensor moved or was written (optimizer step, load_state_dict)
         sd = self.state_dict(keep_vars=True)
         if self.pe == "rope":  # the rotary tables are not state (motion_module.py:221-225) but the engine reads them like weights
@@ -587,6 +591,16 @@ class endodav(nn.Module):
             _lib.check(lib.edv_prepare(C.c_void_p(nat.handle), C.c_void_p(_lib.stream_ptr(device))), "edv_prepare")
             nat.sig = sig
         return nat.handle
+
+    def _new_lane(self) -> int:
+        """A lane id no one else uses (lane 0 is ``model(x)``'s own): one engine context per (device, lane), and a context must never run on two
+        streams at once -- its workspace, stream-K counters and kept state are single-user."""
+        self._lane_seq = getattr(self, "_lane_seq", 0) + 1
+        return self._lane_seq
+
+    def _drop_lane(self, lane: int) -> None:
+        for key in [k for k in self._native if k.endswith(f"#{lane}")]:
+            del self._native[key]  # _NativeCtx.__del__ destroys the engine context (and frees its workspace)
 
     def _dash_layers(self):
         return [m for m in self.modules() if isinstance(m, DashLinear)]
@@ -629,8 +643,11 @@ class endodav(nn.Module):
         return [(ph * m, pw * m) for m in (16, 8, 4, 2)]
 
     # -------------------------------------------------------------------------------------
-    def forward(self, x: torch.Tensor) -> Dict[Tuple[str, int], torch.Tensor]:
-        """``x``: [B, T, 3, H, W] float32 in [0, 1] on a ROCm device → {("disp", s): [B*T, 1, h_s, w_s]}."""
+    def forward(self, x: torch.Tensor, lane: int = 0) -> Dict[Tuple[str, int], torch.Tensor]:
+        """``x``: [B, T, 3, H, W] float32 in [0, 1] on a ROCm device → {("disp", s): [B*T, 1, h_s, w_s]}.  ``lane`` (not in the reference): which
+        engine context of the device runs the clip -- inference only, used by ``pipeline.ClipsInFlight`` to keep consecutive clips in flight."""
+        if lane and (torch.is_grad_enabled() or self.lora_type == "dash"):
+            raise RuntimeError("lanes > 0 run inference under torch.no_grad() only (one set of kept activations / one dash counter per model)")
         if x.dim() != 5 or x.shape[2] != 3:
             raise ValueError(f"expected a clip [B, T, 3, H, W], got {tuple(x.shape)}")
         if not x.is_cuda:
@@ -639,7 +656,7 @@ class endodav(nn.Module):
             raise NotImplementedError("use_bn=True is built for eval() only: train-mode BatchNorm (batch statistics, running-average updates, "
                                       "util/blocks.py:80-86) is not; no reference script sets use_bn")
         train_names: List[str] = []
-        if torch.is_grad_enabled():
+        if torch.is_grad_enabled() and lane == 0:
             if x.requires_grad:
                 raise NotImplementedError("libendodav_hip does not produce the gradient of the input clip (nothing in the reference asks for it)")
             train_names = self._trainable_names()
@@ -655,13 +672,13 @@ class endodav(nn.Module):
             sd = self.state_dict(keep_vars=True)
             outs = _EdvFunction.apply(self, x, tuple(train_names), *[sd[n] for n in train_names])
         else:
-            outs = self._run_native(x, train=False)
+            outs = self._run_native(x, train=False, lane=lane)
         return {("disp", s): outs[s] for s in range(4)}
 
-    def _run_native(self, x: torch.Tensor, train: bool):
+    def _run_native(self, x: torch.Tensor, train: bool, lane: int = 0):
         B, T, _, H, W = x.shape
         with torch.cuda.device(x.device):
-            ctx = self._ensure_ctx(x.device)
+            ctx = self._ensure_ctx(x.device, lane)
             lib = _lib.load()
             _lib.check(lib.edv_set_train(C.c_void_p(ctx), int(train)), "edv_set_train")
             outs = [torch.empty((B * T, 1, h, w), device=x.device, dtype=torch.float32) for (h, w) in self.output_shapes()]

@@ -14,6 +14,115 @@ from typing import Callable, Dict, Iterator, List, Optional, Sequence, Tuple
 import torch
 
 
+class InFlight:
+    """One submitted clip: ``result()`` makes the caller's current stream wait for it and returns its output dict."""
+
+    def __init__(self, out: Dict, done: torch.cuda.Event, pool: List[torch.cuda.Event]):
+        self._out, self._done, self._pool = out, done, pool
+
+    def result(self) -> Dict:
+        cur = torch.cuda.current_stream(next(iter(self._out.values())).device)
+        cur.wait_event(self._done)
+        for o in self._out.values():
+            o.record_stream(cur)  # allocated on the lane's stream, consumed on this one
+        return self._out
+
+    def synchronize(self) -> Dict:
+        self._done.synchronize()
+        return self._out
+
+    def __del__(self):
+        # the event goes back to its lane's pool instead of being destroyed: destroying an event whose work is still in flight made the host wait
+        # for it on this platform (the loop then kept one clip fewer in flight than asked for)
+        try:
+            self._pool.append(self._done)
+        except Exception:
+            pass
+
+
+class ClipsInFlight:
+    """Consecutive clips of an inference stream are independent, so clip k+1's encoder can start while clip k is still in its
+    DPT head: ``depth`` engine contexts of one model (own workspaces, the same bound parameters) take the clips round-robin, each on its own HIP
+    stream.  What that buys is what a short clip leaves idle on 256 CUs -- launch ramps, tails, the head's small grids: ViT-S 518x518 T=8
+    +5.4 % with 2 and +8.9 % with 3 clips in flight, every output bit-identical to the one-at-a-time result; at ViT-B T=16 the kernels fill the
+    part alone and co-residency costs 1-2 % (profiles/r03_notes.txt), hence ``auto_depth``.  Memory: one workspace per lane (1.6 GB at ViT-S T=8),
+    released by ``close()``.  The lanes are this object's own: an engine context is single-user (workspace, stream-K arrival counters), so neither
+    ``model(x)`` (lane 0) nor another ClipsInFlight ever shares one, and they may all run beside each other.
+    Full overlap needs the clips to come from a stream other than PyTorch's default one (or ``resident=True``): an event recorded on the default
+    (null) stream orders it against every other stream on this platform, which keeps one clip fewer in flight (measured: no gain at depth 3).
+
+        flight = ClipsInFlight(model, device)            # depth: auto_depth(model, T) on the first clip
+        handles = [flight.submit(x) for x in clips]      # returns at once; x must stay unmodified until the result is taken
+        maps = handles[0].result()                       # the current stream now waits for clip 0 only
+
+    The reference has no counterpart (one synchronous forward per clip, evaluate_depth_video.py:163-168)."""
+
+    def __init__(self, model, device, depth: Optional[int] = None):
+        self.model, self.dev = model, torch.device(device)
+        self.depth = None if depth is None else max(1, int(depth))
+        self.streams: List[torch.cuda.Stream] = []
+        self.lanes: List[int] = []                      # this object's own engine contexts of the model (never lane 0, never shared)
+        self._ready: List[torch.cuda.Event] = []        # one per lane, re-recorded by every submit
+        self._pool: List[List[torch.cuda.Event]] = []   # completion events per lane, recycled by InFlight.__del__
+        self._k = 0
+
+    def close(self) -> None:
+        """Wait for the clips in flight and release the lanes' engine contexts (their workspaces)."""
+        for s in self.streams:
+            s.synchronize()
+        for lane in self.lanes:
+            self.model._drop_lane(lane)
+        self.lanes, self.streams, self._ready, self._pool = [], [], [], []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def auto_depth(model, frames: int) -> int:
+        """Lanes while one clip is too small to fill the part (token rows x width of the encoder), 1 otherwise -- the measured sign change lies
+        at about ViT-S T=16 / ViT-B T=8 (21 920 rows x 384 resp. 10 960 x 768: +3 % / +-0); larger clips lose 1-2 %: profiles/r03_notes.txt."""
+        ph, pw = model.image_shape[0] // 14, model.image_shape[1] // 14
+        rows = frames * (ph * pw + 1)
+        return 3 if rows * model.pretrained.embed_dim <= 22_000 * 384 else 1
+
+    def submit(self, x: torch.Tensor, resident: bool = False) -> InFlight:
+        """Enqueue one clip [B, T, 3, H, W] (device tensor).  ``resident``: the clip's producer finished long ago (a dataset tensor already in HBM),
+        so the lane need not wait for the caller's stream."""
+        if self.depth is None:
+            self.depth = self.auto_depth(self.model, x.shape[0] * x.shape[1])
+        while len(self.streams) < self.depth:
+            self.streams.append(torch.cuda.Stream(device=self.dev))
+            self.lanes.append(self.model._new_lane())
+            self._ready.append(torch.cuda.Event())
+            self._pool.append([])
+        lane = self._k % self.depth
+        self._k += 1
+        s = self.streams[lane]
+        with torch.cuda.device(self.dev), torch.no_grad():
+            if not resident:
+                self._ready[lane].record(torch.cuda.current_stream(self.dev))
+                s.wait_event(self._ready[lane])  # the clip was produced on the caller's stream
+            with torch.cuda.stream(s):
+                out = self.model(x, lane=self.lanes[lane])  # the lane's own context and workspace; its previous clip is ordered before this one by the stream
+                done = self._pool[lane].pop() if self._pool[lane] else torch.cuda.Event()
+                done.record(s)
+            x.record_stream(s)
+        return InFlight(out, done, self._pool[lane])
+
+    def run(self, clips, resident: bool = False) -> Iterator[Dict]:
+        """Outputs of ``clips`` (device tensors) in order, ``depth`` of them in flight."""
+        pending: List[InFlight] = []
+        for x in clips:
+            pending.append(self.submit(x, resident))
+            if len(pending) >= self.depth:
+                yield pending.pop(0).result()
+        while pending:
+            yield pending.pop(0).result()
+
+
 class ClipPipeline:
     """``run(clips)``: feed host clips [B, T, 3, H, W] (float32, any iterable) through ``forward`` and yield, in order, the maps of
     each clip as pinned host tensors (valid until the next result is taken).  ``forward`` is the model (or any callable

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EDV_ABI_VERSION 7 /* 7: the split-bf16 experiment entry points (edv_gemm_sb, edv_conv3x3_sb) left the library */
+#define EDV_ABI_VERSION 8 /* 8: edv_debug_fill_lds (test hook); 7: the split-bf16 experiment entry points left the library */
 
 enum edv_lora_type { EDV_LORA_NONE = 0, EDV_LORA_LORA = 1, EDV_LORA_DVLORA = 2, EDV_LORA_SSB = 3, EDV_LORA_DASH = 4 };
 
@@ -206,6 +206,10 @@ int edv_geglu(const float *x_dev, float *y_dev, int64_t M, int32_t inner, void *
 
 /* Bilinear resize, align_corners=True, channels-last [F,H,W,C] -> [F,OH,OW,C]
  * (every F.interpolate of the model). */
+/* Test hook: fills the whole LDS (160 KB) of every CU with `value`; LDS keeps its contents between kernels, so a kernel that depends on LDS bytes it
+ * never wrote shows.  No reference counterpart. */
+int edv_debug_fill_lds(float value, void *stream);
+
 int edv_bilinear(const float *x_dev, float *y_dev, int32_t F, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void *stream);
 
 /* y[m] = act(x[m,:]·w + b) for the final 1x1 convs; act: 0 none, 2 ReLU, 3 sigmoid, 4 sigmoid(-v). */

@@ -265,8 +265,9 @@ def test_gemm_ragged_edges_stay_inside_guard_bands(lib, cuda, M, N, K, act, use_
     bigR, Rd = _guarded(R, cuda, float("nan")) if R is not None else (None, None)  # a read past the residual's end would put a NaN into C
     ws, nbytes = gemm_ws(lib, cuda) if split else (None, 0)
     g = None if gamma is None else gamma.to(cuda)
-    _lib.check(lib.edv_gemm(A.to(cuda).data_ptr(), W.to(cuda).data_ptr(), Cd.data_ptr(), M, N, K, bias.to(cuda).data_ptr(), act, _lib.ptr(g), _lib.ptr(Rd),
-                            _lib.ptr(ws), nbytes, st()), "edv_gemm")
+    Ad, Wd, bd = A.to(cuda), W.to(cuda), bias.to(cuda)  # (named: a temporary would be freed -- and its block reused -- before the kernel runs)
+    _lib.check(lib.edv_gemm(Ad.data_ptr(), Wd.data_ptr(), Cd.data_ptr(), M, N, K, bd.data_ptr(), act, _lib.ptr(g), _lib.ptr(Rd), _lib.ptr(ws), nbytes, st()),
+               "edv_gemm")
     torch.cuda.synchronize()
     assert _guards_intact(bigC, M * N, SENT), "a store escaped the C descriptor"
     close(Cd, ref, 3e-6, f"gemm {M}x{N}x{K} in guard bands")
@@ -344,6 +345,23 @@ def test_attn_spatial(lib, cuda, Fr, N, heads):
     o = torch.full((Fr * N, D), float("nan"), device=cuda)
     attn_spatial(lib, cuda, qd, o, Fr, N, heads)
     close(o, ref, 5e-6, "attn_spatial")
+
+
+def test_attention_on_poisoned_lds(lib, cuda):
+    """Key / value rows past the sequence end (N % 64 != 0) reach LDS as zeros written by the DMA itself (out-of-range lanes of buffer_load ... lds,
+    scratch/ubench/lds_dma_oob.hip); the kernel no longer clears its stages first.  With every CU's LDS full of NaN beforehand a stale byte entering
+    the PV product (0 x NaN) would show in the output."""
+    for Fr, N, heads in [(2, 1370, 6), (3, 10, 1), (1, 129, 12), (8, 1370, 6)]:
+        D = heads * 64
+        qkv = rnd(Fr * N, 3 * D, seed=1, scale=2.0)
+        t = qkv.double().reshape(Fr, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
+        q, k, v = t[0] * 64 ** -0.5, t[1], t[2]
+        ref = ((q @ k.transpose(-2, -1)).softmax(-1) @ v).transpose(1, 2).reshape(Fr * N, D)
+        qd = qkv.to(cuda)
+        o = torch.full((Fr * N, D), float("nan"), device=cuda)
+        _lib.check(lib.edv_debug_fill_lds(float("nan"), st()), "edv_debug_fill_lds")
+        attn_spatial(lib, cuda, qd, o, Fr, N, heads)
+        close(o, ref, 5e-6, f"attn_spatial after an LDS poison, N={N}")
 
 
 def test_attn_spatial_workspace_contract(lib, cuda):

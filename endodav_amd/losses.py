@@ -108,6 +108,174 @@ def photometric_loss(disps: Dict[Tuple[str, int], torch.Tensor], frames: torch.T
     return total / len(scales)
 
 
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The trainer's loss as the trainer computes it: generate_images_pred + compute_losses of
+# trainer_end_to_end_video.py:808-971 with the side networks' outputs as INPUTS (pose, optical-flow and appearance networks are outside the hot
+# path: SURVEY.md section 2.1 rows 12-15).  `photometric_loss` above is the round-2 subset (neighbours taken from the clip itself, no mask, raw
+# frame as target); this is the full per-scale sum:
+#
+#   loss_reprojection   sum(m * (0.85 SSIM + 0.15 L1)(color_warp(fid), refined(s, fid))) / sum(m)     m = occu_mask_backward(0, fid), detached   (:940-941)
+#   loss_transform      sum(m * mean_c |refined(s, fid) - registration(0, fid)|) / sum(m)                                            (:942-943)
+#   loss_cvt            get_smooth_bright(transform_high(s, fid), color(0, 0), registration(s, fid), m)       utils/layers.py:239-264  (:944-945)
+#   loss_depth_reproj   mean over sampled_depth > 1e-3 of |z of frame i's points in frame i+-1 - depth(i+-1) sampled there|          (:863-877)
+#   loss_depth_flow     mean over warp_depth > 1e-3 of |depth(i) carried along the optical flow - depth(i+-1)|                      (:879-890)
+#   loss_smooth         get_smooth_loss(disp_s / (mean + 1e-7), color(0, s)) at the resolution of color(0, s)                       (:929-933, :949-951)
+#   per scale: rep / 2 + tc * tr / 2 + ts * cvt / 2 + ds * smooth / 2^s + tw * (dr * reproj / 2 + df * flow / 2);  total = mean over the scales (:953-968)
+#
+# Everything the reference's autograd would reach is differentiable here too: the four disparity maps, refined, transform_high, the poses and --
+# with learn_intrinsics (options.py:94-97, default on) -- K and inv_K.  registration and the occlusion mask are detached in the reference.
+from dataclasses import dataclass, field
+
+
+@dataclass
+class TrainerLossWeights:
+    """options.py defaults; ``tune_temporal`` is the trainer's phase flag (temporal_weight, trainer_end_to_end_video.py:951)."""
+    disparity_smoothness: float = 1e-3
+    transform_constraint: float = 0.01
+    transform_smoothness: float = 0.01
+    depth_reproj: float = 0.0
+    depth_flow: float = 0.0
+    tune_temporal: bool = False
+    min_depth: float = MIN_DEPTH
+    max_depth: float = MAX_DEPTH
+
+
+FIDS = (-1, 1)  # opt.frame_ids[1:]
+
+
+def smooth_bright(transform: torch.Tensor, target: torch.Tensor, pred: torch.Tensor, occu_mask: torch.Tensor) -> torch.Tensor:
+    """get_smooth_bright (utils/layers.py:239-264): first-order smoothness of the appearance-flow map, damped where the residue has edges, masked."""
+    gtx = torch.mean(torch.abs(transform[:, :, :, :-1] - transform[:, :, :, 1:]), 1, keepdim=True)
+    gty = torch.mean(torch.abs(transform[:, :, :-1, :] - transform[:, :, 1:, :]), 1, keepdim=True)
+    res = target - pred
+    grx = torch.mean(torch.abs(res[:, :, :, :-1] - res[:, :, :, 1:]), 1, keepdim=True)
+    gry = torch.mean(torch.abs(res[:, :, :-1, :] - res[:, :, 1:, :]), 1, keepdim=True)
+    mx, my = occu_mask[:, :, :, :-1], occu_mask[:, :, :-1, :]
+    return (gtx * torch.exp(-grx) * mx).sum() / mx.sum() + (gty * torch.exp(-gry) * my).sum() / my.sum()
+
+
+def flow_sample(src: torch.Tensor, flow: torch.Tensor, padding: str) -> torch.Tensor:
+    """SpatialTransformer.forward (utils/layers.py:387-426): sample ``src`` at (pixel + flow); flow[:, 0] is the row (y) displacement."""
+    n, _, H, W = flow.shape
+    ys, xs = torch.meshgrid(torch.arange(H, device=flow.device, dtype=flow.dtype), torch.arange(W, device=flow.device, dtype=flow.dtype), indexing="ij")
+    ny = 2 * ((ys + flow[:, 0]) / (H - 1) - 0.5)
+    nx = 2 * ((xs + flow[:, 1]) / (W - 1) - 0.5)
+    return F.grid_sample(src, torch.stack([nx, ny], -1), mode="bilinear", padding_mode=padding, align_corners=True)
+
+
+def trainer_losses(disps: Dict[Tuple[str, int], torch.Tensor], inp: Dict, weights: TrainerLossWeights = TrainerLossWeights(),
+                   scales: Sequence[int] = (0, 1, 2, 3)) -> Dict[str, torch.Tensor]:
+    """``inp`` keys (N = B*T flattened frames, as the trainer flattens them, trainer_end_to_end_video.py:406-409):
+        ("color", 0, s)            [N, 3, H >> s, W >> s]      frames at the loss scales (s = 0: the frame itself)
+        ("color", -1, 0), ("color", 1, 0)                     [N, 3, H, W] the previous / next frame of every frame
+        "K", "inv_K"               [N, 4, 4];   ("cam_T_cam", 0, fid) [N, 4, 4]
+        ("refined", s, fid), ("registration", s, fid), ("transform", "high", s, fid)   [N, 3, H, W]
+        ("occu_mask_backward", 0, fid)   [N, 1, H, W];   ("position", "high", s, fid)   [N, 2, H, W]   (only for depth_flow)
+    Returns the trainer's ``losses`` dict (tensors): "loss", "loss/{s}", "loss/loss_reprojection/{s}", ... (:960-966)."""
+    w = weights
+    frame = inp[("color", 0, 0)]
+    n, _, H, W = frame.shape
+    pix = pixel_grid(n, H, W, frame.device, frame.dtype)
+    tw = 1.0 if w.tune_temporal else 0.0
+    out: Dict[str, torch.Tensor] = {}
+    total = frame.new_zeros(())
+    for s in scales:
+        disp_s = disps[("disp", s)]
+        d_full = disp_s if disp_s.shape[-2:] == (H, W) else F.interpolate(disp_s, [H, W], mode="bilinear", align_corners=True)
+        _, depth = disp_to_depth(d_full, w.min_depth, w.max_depth)
+        cam = backproject(depth, inp["inv_K"], pix)
+        rep = tr = cvt = drp = dfl = frame.new_zeros(())
+        for fid in FIDS:
+            T = inp[("cam_T_cam", 0, fid)]
+            P = torch.matmul(inp["K"], T)[:, :3, :]
+            camp = torch.matmul(P, cam)
+            grid = project(cam, inp["K"], T, H, W)
+            warped = F.grid_sample(inp[("color", fid, 0)], grid, padding_mode="border", align_corners=True)
+            m = inp[("occu_mask_backward", 0, fid)].detach()
+            refined = inp[("refined", s, fid)]
+            rep = rep + (reprojection_loss(warped, refined) * m).sum() / m.sum()
+            tr = tr + (torch.abs(refined - inp[("registration", 0, fid)].detach()).mean(1, True) * m).sum() / m.sum()
+            cvt = cvt + smooth_bright(inp[("transform", "high", s, fid)], frame, inp[("registration", s, fid)].detach(), m)
+            if tw * w.depth_reproj != 0.0:
+                z = camp[:, 2:3, :].reshape(n, 1, H, W)
+                if fid == 1:
+                    tgt, coords, src = depth[1:], grid[:-1], z[:-1]
+                else:
+                    tgt, coords, src = depth[:-1], grid[1:], z[1:]
+                sampled = F.grid_sample(tgt, coords, padding_mode="zeros", align_corners=True)
+                drp = drp + torch.abs(src - sampled)[sampled > 1e-3].mean()
+            if tw * w.depth_flow != 0.0:
+                flow = inp[("position", "high", s, fid)]
+                if fid == 1:
+                    origin, fl, fwd = depth[:-1], flow[:-1], depth[1:]
+                else:
+                    origin, fl, fwd = depth[1:], flow[1:], depth[:-1]
+                warp = flow_sample(origin, fl, "zeros")
+                dfl = dfl + torch.abs(warp - fwd)[warp > 1e-3].mean()
+        color = inp[("color", 0, s)]
+        d_c = disp_s if disp_s.shape[-2:] == color.shape[-2:] else F.interpolate(disp_s, list(color.shape[-2:]), mode="bilinear", align_corners=True)
+        sm = smooth_loss(d_c / (d_c.mean(2, True).mean(3, True) + 1e-7), color)
+        terms = {"loss_reprojection": rep / 2.0, "loss_transform": w.transform_constraint * tr / 2.0, "loss_cvt": w.transform_smoothness * cvt / 2.0,
+                 "loss_smooth": w.disparity_smoothness * sm / (2 ** s), "loss_depth_reproj": tw * w.depth_reproj * drp / 2.0,
+                 "loss_depth_flow": tw * w.depth_flow * dfl / 2.0}
+        loss_s = sum(terms.values())
+        total = total + loss_s
+        out[f"loss/{s}"] = loss_s
+        for k, v in terms.items():
+            out[f"loss/{k}/{s}"] = v
+    out["loss"] = total / len(scales)
+    return out
+
+
+def synthetic_trainer_inputs(n: int, H: int, W: int, device="cpu", seed: int = 0, dtype=torch.float32) -> Dict:
+    """Everything ``trainer_losses`` takes besides the disparity maps, from the portable counter-based generator (so the golden fixtures, the tests
+    and bench.py --train see the same numbers on any machine): a tissue-like clip of n + 2 frames (frame i's neighbours are frames i - 1 / i + 1 of
+    it, the trainer's dataset layout, datasets/scared_video_dataset.py:289-296), pinhole intrinsics, small relative poses that differ per frame, and
+    stand-ins for the side networks' outputs with the statistics the reference's own expressions give them: registration = the neighbour plus a
+    small error, transform_high = a low-amplitude field, refined = clamp(transform_high * mask + frame, 0, 1) (trainer :789-790), a ~90 % occlusion
+    mask, optical flow of a pixel or two."""
+    from . import synth
+
+    clip = torch.from_numpy(synth.synth_clip(1, n + 2, H, W, seed=seed, kind="tissue")[0]).to(dtype)  # [n + 2, 3, H, W]
+    u = lambda key, shape, lo, hi: torch.from_numpy(synth.uniform(f"trainer_loss:{seed}:{key}", shape, lo, hi)).to(dtype)
+    inp: Dict = {}
+    frame = clip[1:-1].contiguous()
+    for s in range(4):
+        inp[("color", 0, s)] = frame if s == 0 else F.interpolate(frame, [H >> s, W >> s], mode="bilinear", align_corners=False)
+    inp[("color", -1, 0)], inp[("color", 1, 0)] = clip[:-2].contiguous(), clip[2:].contiguous()
+    K = torch.eye(4, dtype=dtype).repeat(n, 1, 1)
+    K[:, 0, 0] = 0.82 * W * (1 + u("fx", (n,), -0.02, 0.02))
+    K[:, 1, 1] = 1.02 * H * (1 + u("fy", (n,), -0.02, 0.02))
+    K[:, 0, 2], K[:, 1, 2] = 0.5 * W, 0.5 * H
+    inp["K"], inp["inv_K"] = K, torch.linalg.inv(K.double()).to(dtype)
+    for fid in FIDS:
+        T = torch.eye(4, dtype=dtype).repeat(n, 1, 1)
+        ang = u(f"ang{fid}", (n,), -0.02, 0.02)
+        T[:, 0, 0], T[:, 0, 2], T[:, 2, 0], T[:, 2, 2] = torch.cos(ang), torch.sin(ang), -torch.sin(ang), torch.cos(ang)
+        T[:, :3, 3] = u(f"t{fid}", (n, 3), -0.04, 0.04) + torch.tensor([0.05 * fid, 0.0, -0.02 * fid], dtype=dtype)
+        inp[("cam_T_cam", 0, fid)] = T
+        m = (u(f"mask{fid}", (n, 1, H, W), 0.0, 1.0) > 0.1).to(dtype)
+        inp[("occu_mask_backward", 0, fid)] = m
+        for s in range(4):
+            inp[("registration", s, fid)] = (inp[("color", fid, 0)] + u(f"reg{s}{fid}", (n, 3, H, W), -0.03, 0.03)).clamp(0, 1)
+            th = u(f"tr{s}{fid}", (n, 3, H, W), -0.04, 0.04)
+            inp[("transform", "high", s, fid)] = th
+            inp[("refined", s, fid)] = torch.clamp(th * m + frame, min=0.0, max=1.0)
+            inp[("position", "high", s, fid)] = u(f"pos{s}{fid}", (n, 2, H, W), -1.5, 1.5)
+    return {k: v.to(device) for k, v in inp.items()}
+
+
+def synthetic_disps(n: int, sizes: Sequence[Tuple[int, int]], device="cpu", seed: int = 0, dtype=torch.float32) -> Dict[Tuple[str, int], torch.Tensor]:
+    """Four smooth positive disparity maps [n, 1, h_s, w_s] in (0.05, 0.9) (sigmoid-like range of the heads)."""
+    from . import synth
+
+    out = {}
+    for s, (h, w) in enumerate(sizes):
+        low = torch.from_numpy(synth.uniform(f"trainer_loss:{seed}:disp{s}", (n, 1, max(h // 6, 2), max(w // 6, 2)), 0.05, 0.9)).to(dtype)
+        out[("disp", s)] = F.interpolate(low, [h, w], mode="bilinear", align_corners=True).contiguous().to(device)
+    return out
+
+
 def synthetic_camera(n: int, H: int, W: int, device, dtype=torch.float32):
     """Intrinsics of a pinhole camera normalised like the reference's datasets (fx = 0.82 W, fy = 1.02 H, centre = half size:
     datasets/scared_dataset.py K) and small forward / backward relative poses, for synthetic fine-tune steps."""

@@ -258,6 +258,103 @@ def make_loss_kat():
     print(f"loss_kat: ssim mean {out['ssim'].mean():.5f}, smooth {out['smooth']:.6f}, total {out['total']:.6f}; wrote {os.path.getsize(path)} B")
 
 
+TRAINER_LOSS_CASE = dict(n=4, H=32, W=48, disp_sizes=[(28, 42), (14, 21), (7, 10), (4, 5)], seed=3,
+                         weights=dict(disparity_smoothness=1e-3, transform_constraint=0.01, transform_smoothness=0.01, depth_reproj=1e-2, depth_flow=1e-3,
+                                      tune_temporal=True))
+
+
+def reference_trainer_methods():
+    """The reference's OWN generate_images_pred / compute_reprojection_loss / compute_losses (trainer_end_to_end_video.py:808-971), compiled from the
+    source where it lies.  The module itself cannot be imported here -- its top pulls in tensorboardX, torchvision.models and the dataset readers
+    (trainer :1-20), none of which the loss needs -- so the three methods are taken out of the file's syntax tree and executed in a namespace that
+    holds what they use: torch, F and the reference's own utils.layers (imported for real).  Nothing of the file is written anywhere."""
+    import ast
+
+    import utils.layers as Lr
+
+    path = os.path.join(REFERENCE, "trainer_end_to_end_video.py")
+    with open(path) as f:
+        tree = ast.parse(f.read(), filename=path)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "Trainer")
+    want = ("generate_images_pred", "compute_reprojection_loss", "compute_losses")
+    mod = ast.Module(body=[n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name in want], type_ignores=[])
+    assert len(mod.body) == 3
+    ns = {k: getattr(Lr, k) for k in dir(Lr) if not k.startswith("__")}
+    ns.update(torch=torch, F=torch.nn.functional)
+    exec(compile(mod, path, "exec"), ns)
+    return {k: ns[k] for k in want}, Lr
+
+
+def make_trainer_loss_kat():
+    """Known answers of the trainer's whole loss: the reference's own methods on a synthetic inputs / outputs dict; the
+    restatement endodav_amd/losses.py::trainer_losses must agree before anything is written (values 1e-6, gradients 2e-5 of scale)."""
+    import types as _types
+
+    from endodav_amd import losses as mine
+
+    C = TRAINER_LOSS_CASE
+    n, H, W = C["n"], C["H"], C["W"]
+    fns, Lr = reference_trainer_methods()
+    inp = mine.synthetic_trainer_inputs(n, H, W, seed=C["seed"])
+    disps = mine.synthetic_disps(n, C["disp_sizes"], seed=C["seed"])
+    wts = mine.TrainerLossWeights(**C["weights"])
+    leaves = {}
+
+    def leaf(key, t):
+        leaves[key] = t.clone().requires_grad_(True)
+        return leaves[key]
+
+    # the reference's dicts: `inputs` from the dataset, `outputs` from the depth model (disp) and the side networks
+    inputs = {("color", 0, s): inp[("color", 0, s)] for s in range(4)}
+    inputs.update({("color", fid, 0): inp[("color", fid, 0)] for fid in (-1, 1)})
+    outputs = {("disp", s): leaf(("disp", s), disps[("disp", s)]) for s in range(4)}
+    outputs[("K", 0)], outputs[("inv_K", 0)] = leaf("K", inp["K"]), leaf("inv_K", inp["inv_K"])  # learn_intrinsics (options.py:94-97)
+    for fid in (-1, 1):
+        outputs[("cam_T_cam", 0, fid)] = leaf(("cam_T_cam", 0, fid), inp[("cam_T_cam", 0, fid)])
+        outputs[("occu_mask_backward", 0, fid)] = inp[("occu_mask_backward", 0, fid)]
+        for s in range(4):
+            outputs[("refined", s, fid)] = leaf(("refined", s, fid), inp[("refined", s, fid)])
+            outputs[("transform", "high", s, fid)] = leaf(("transform", "high", s, fid), inp[("transform", "high", s, fid)])
+            outputs[("registration", s, fid)] = inp[("registration", s, fid)]
+            outputs[("position", "high", s, fid)] = inp[("position", "high", s, fid)]
+    opt = _types.SimpleNamespace(scales=[0, 1, 2, 3], v1_multiscale=False, height=H, width=W, min_depth=0.1, max_depth=150.0, learn_intrinsics=True,
+                                 frame_ids=[0, -1, 1], pose_model_type="separate_resnet", no_ssim=False, **{k: v for k, v in C["weights"].items() if k != "tune_temporal"})
+    me = _types.SimpleNamespace(opt=opt, num_scales=4, tune_temporal=C["weights"]["tune_temporal"], ssim=Lr.SSIM(),
+                                backproject_depth={0: Lr.BackprojectDepth(n, H, W)}, project_3d={0: Lr.Project3D(n, H, W)},
+                                position_depth={0: Lr.optical_flow((H, W), n, H, W)}, spatial_transform=Lr.SpatialTransformer((H, W)))
+    me.compute_reprojection_loss = _types.MethodType(fns["compute_reprojection_loss"], me)
+    fns["generate_images_pred"](me, inputs, outputs)
+    ref = fns["compute_losses"](me, inputs, outputs)
+    ref["loss"].backward()
+    # the restatement on the same numbers
+    mine_leaves = {k: v.detach().clone().requires_grad_(True) for k, v in leaves.items()}
+    inp2 = dict(inp)
+    inp2["K"], inp2["inv_K"] = mine_leaves["K"], mine_leaves["inv_K"]
+    for k in mine_leaves:
+        if isinstance(k, tuple) and k[0] != "disp":
+            inp2[k] = mine_leaves[k]
+    got = mine.trainer_losses({("disp", s): mine_leaves[("disp", s)] for s in range(4)}, inp2, wts)
+    got["loss"].backward()
+    out = {}
+    worst_v = worst_g = 0.0
+    for k, v in ref.items():
+        rv = float(v)
+        worst_v = max(worst_v, abs(float(got[k]) - rv) / max(abs(rv), 1e-12))
+        out["value:" + k] = np.float64(rv)
+    for k, t in leaves.items():
+        g, gm = t.grad, mine_leaves[k].grad
+        assert g is not None and gm is not None, k
+        worst_g = max(worst_g, float((g - gm).abs().max() / g.abs().max().clamp_min(1e-30)))
+        name = "grad:" + (k if isinstance(k, str) else ":".join(str(x) for x in k))
+        out[name] = g.numpy()
+    print(f"trainer_loss_kat: restatement vs the reference's compute_losses: values {worst_v:.2e}, gradients {worst_g:.2e} of scale")
+    if worst_v > 1e-6 or worst_g > 2e-5:
+        raise SystemExit("trainer_losses disagrees with the reference: fixture not written")
+    path = os.path.join(HERE, "trainer_loss_kat.npz")
+    np.savez_compressed(path, **out)
+    print(f"trainer_loss_kat: loss {float(ref['loss']):.6f}, {len(out)} arrays; wrote {os.path.getsize(path)} B")
+
+
 def dump_state_keys(ref):
     """state_dict key -> shape listings of the reference for the drop-in check."""
     import json
@@ -323,7 +420,9 @@ def main(argv):
         make_metrics_kat()
     if not argv or "losses" in argv:
         make_loss_kat()
-    names = [a for a in argv if a not in ("video", "keys", "metrics", "losses")] if argv else list(CASES)
+    if not argv or "trainer_losses" in argv:
+        make_trainer_loss_kat()
+    names = [a for a in argv if a not in ("video", "keys", "metrics", "losses", "trainer_losses")] if argv else list(CASES)
     torch.set_num_threads(8)
     for name in names:
         kwargs, (B, T, H, W), kind, store = CASES[name]

@@ -4,7 +4,7 @@ ARCH     ?= gfx950
 CSRC     := endodav_amd/csrc
 OUT      := endodav_amd/lib/libendodav_hip.so
 SRCS     := $(CSRC)/gemm.hip $(CSRC)/gemm_dma.hip $(CSRC)/conv_dma.hip $(CSRC)/attn_spatial.hip $(CSRC)/attn_spatial_bwd.hip $(CSRC)/norms.hip $(CSRC)/temporal.hip \
-            $(CSRC)/resample.hip $(CSRC)/prep.hip $(CSRC)/bwd.hip $(CSRC)/wgrad.hip $(CSRC)/loss.hip $(CSRC)/engine.hip $(CSRC)/api.hip
+            $(CSRC)/resample.hip $(CSRC)/prep.hip $(CSRC)/bwd.hip $(CSRC)/wgrad.hip $(CSRC)/loss.hip $(CSRC)/loss_trainer.hip $(CSRC)/engine.hip $(CSRC)/api.hip
 OBJS     := $(SRCS:$(CSRC)/%.hip=build/%.o)
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++20 -fPIC -Wall -Wno-unused-function -fno-gpu-rdc
 
@@ -14,7 +14,7 @@ all: $(OUT)
 # first canonicalised by an extra v_max_f32 (VALU instructions cost matrix-pipe time)
 build/attn_spatial.o: HIPFLAGS += -fno-honor-nans
 
-build/%.o: $(CSRC)/%.hip $(CSRC)/ops.hpp $(CSRC)/common.hpp $(CSRC)/gemm_common.hpp include/endodav_hip.h
+build/%.o: $(CSRC)/%.hip $(CSRC)/ops.hpp $(CSRC)/common.hpp $(CSRC)/gemm_common.hpp $(CSRC)/loss_common.hpp include/endodav_hip.h
 	@mkdir -p build
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 

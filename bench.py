@@ -20,9 +20,9 @@ Rank 0 prints ONE JSON line: value = total frames of all ranks / max-over-ranks 
                       patchify): algorithmic bytes over launch time against the 8 TB/s HBM3E peak
   cpu_baseline        the oracle (PyTorch-CPU restatement, kind "port") timed on this box's host cores on a bounded
                       sample of the same workload (rank 0, N = 1 only): median of 5 clips at n = the box's cores and at n = 8.
---train times the fine-tune step (BASELINE.json config 4 with --encoder vitb --T 16 --image 224x280): forward + the photometric
-loss (SSIM + L1 reprojection on the two warped neighbours, smoothness: fused in HIP, edv_photometric_loss; --torch-loss = the same as eager PyTorch ops,
---l1-loss = the round-1 stand-in) + HIP backward + ONE in-place all-reduce of the flat gradient buffer + AdamW + weight refresh.
+--train times the fine-tune step (BASELINE.json config 4 with --encoder vitb --T 16 --image 224x280): forward + the trainer's loss
+(trainer_end_to_end_video.py:808-971 with synthetic side-network outputs, fused in HIP: edv_trainer_loss; --torch-loss = the same as eager PyTorch
+ops, --l1-loss = the round-1 stand-in) + HIP backward + ONE in-place all-reduce of the flat gradient buffer + AdamW + weight refresh.
 """
 from __future__ import annotations
 
@@ -70,9 +70,11 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(16, cores): the box's CPU share)")
     ap.add_argument("--train", action="store_true", help="time the fine-tune step instead (forward + photometric loss + HIP backward + gradient "
                     "all-reduce + AdamW on the LoRA factors; BASELINE.json config 4 shape with --encoder vitb --T 16); not the headline metric")
-    ap.add_argument("--l1-loss", action="store_true", help="--train with the round-1 L1 stand-in instead of the photometric loss (A/B of the loss's share)")
-    ap.add_argument("--torch-loss", action="store_true", help="--train with the photometric loss as eager PyTorch ops (endodav_amd/losses.py::photometric_loss) "
-                    "instead of the fused HIP kernels (edv_photometric_loss): what the loss costs on the host framework")
+    ap.add_argument("--l1-loss", action="store_true", help="--train with the round-1 L1 stand-in instead of the trainer's loss (A/B of the loss's share)")
+    ap.add_argument("--torch-loss", action="store_true", help="--train with the trainer's loss as eager PyTorch ops (endodav_amd/losses.py::trainer_losses) "
+                    "instead of the fused HIP kernels (edv_trainer_loss): what the loss costs on the host framework")
+    ap.add_argument("--depth-consistency", action="store_true", help="--train with the depth reprojection / flow consistency terms on (the reference's "
+                    "scripts: --depth_reproj 1e-2 / --depth_flow 1e-3 in the temporal tuning phase); default: the options' defaults, both off")
     args = ap.parse_args()
     hw = [int(v) for v in str(args.image).lower().split("x")]
     args.image_hw = (hw[0], hw[0]) if len(hw) == 1 else (hw[0], hw[1])
@@ -395,31 +397,36 @@ def train_bench(args, model, x, dev, rank, world, kwargs, rehearsal=False):
     params = [p for p in model.parameters() if p.requires_grad]
     opt = torch.optim.AdamW(params, lr=1e-4)
     T, (SH, SW) = args.T, args.image_hw
-    frames = x.flatten(0, 1)  # [B*T, 3, H, W]: the loss compares each frame with its warped neighbours at the frame size
-    cams = [losses.synthetic_camera(T, frames.shape[-2], frames.shape[-1], dev) for _ in range(args.clips)]
-    cam_all = [torch.cat([c[i] for c in cams]) for i in range(4)]
+    # The trainer's whole loss (losses.trainer_losses: masked reprojection against `refined`, loss_transform, get_smooth_bright, per-scale smoothness and,
+    # with --depth-consistency, the two depth-consistency terms of the reference's scripts) on synthetic stand-ins for the side networks' outputs;
+    # every tensor the reference's autograd reaches requires grad (poses, K / inv_K, refined, transform_high), so the fused call produces them all.
+    N = x.shape[0] * x.shape[1]
+    inp = losses.synthetic_trainer_inputs(N, x.shape[-2], x.shape[-1], device=dev, seed=rank)
+    inp[("color", 0, 0)] = x.flatten(0, 1).contiguous()  # the clip the model sees is the loss's frame
+    for s_ in range(1, 4):
+        inp[("color", 0, s_)] = torch.nn.functional.interpolate(inp[("color", 0, 0)], [x.shape[-2] >> s_, x.shape[-1] >> s_], mode="bilinear", align_corners=False)
+    for k in list(inp):
+        if k in ("K", "inv_K") or (isinstance(k, tuple) and k[0] in ("cam_T_cam", "refined", "transform")):
+            inp[k].requires_grad_(True)
+    side_leaves = [v for v in inp.values() if v.requires_grad]
+    wts = losses.TrainerLossWeights(depth_reproj=1e-2, depth_flow=1e-3, tune_temporal=True) if args.depth_consistency else losses.TrainerLossWeights()
     events = not args.no_kernel_events
     lin_from = args.steps - min(LIN_STEPS, args.steps)
     state = {}
-    loss_ms = []
 
     def loss_fn(out):
         if args.l1_loss:
             return sum((o - o.detach().mean()).abs().mean() for o in out.values())
-        if not args.torch_loss:
-            return losses.photometric_loss_hip(out, frames, *cam_all, clips=args.clips)
-        total = 0.0
-        for b in range(args.clips):
-            sl = slice(b * T, (b + 1) * T)
-            K, inv_K, Tp, Tn = cams[b]
-            total = total + losses.photometric_loss({k: v[sl] for k, v in out.items()}, frames[sl], K, inv_K, Tp, Tn)
-        return total / args.clips
+        fn = losses.trainer_losses if args.torch_loss else losses.trainer_losses_hip
+        return fn(out, inp, wts)["loss"]
 
     def step(i):
         if i == lin_from and events:
             model.profile_set(["linear"])
         timed = events and i >= lin_from
         opt.zero_grad(set_to_none=True)
+        for t_ in side_leaves:
+            t_.grad = None
         out = model(x)
         if timed:
             e0, e1, e2 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -460,8 +467,10 @@ def train_bench(args, model, x, dev, rank, world, kwargs, rehearsal=False):
                                   "edv_backward together"}
     if rank == 0:
         frames_n = world * args.clips * T * args.steps
-        loss_name = "L1 stand-in" if args.l1_loss else ("photometric loss (0.85 SSIM + 0.15 L1 on the two warped neighbours + edge-aware smoothness, 4 scales; " +
-                                                        ("eager PyTorch ops)" if args.torch_loss else "fused HIP kernels, edv_photometric_loss)"))
+        loss_name = "L1 stand-in" if args.l1_loss else ("the trainer's loss (trainer_end_to_end_video.py:808-971: masked 0.85 SSIM + 0.15 L1 reprojection against refined, "
+                                                        "loss_transform, get_smooth_bright, smoothness" + (", depth reprojection + flow consistency" if args.depth_consistency else "") +
+                                                        "; 4 scales; side-network outputs synthetic; gradients to disp, poses, K, inv_K, refined, transform_high; " +
+                                                        ("eager PyTorch ops)" if args.torch_loss else "fused HIP kernels, edv_trainer_loss)"))
         line = {
             "metric": f"fine-tune frames/sec ({SH}x{SW}, T={T} clip, LoRA factors trainable)", "value": round(frames_n / dt, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,

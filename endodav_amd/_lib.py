@@ -11,7 +11,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EDV_LIB_PATH") or os.path.join(_HERE, "lib", "libendodav_hip.so")  # override: experiments only
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 LORA_TYPES = {"none": 0, "lora": 1, "dvlora": 2, "ssb": 3, "dash": 4}
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_SIGMOID_NEG = 0, 1, 2, 3, 4
@@ -113,6 +113,8 @@ SIGNATURES = {
     "edv_groupnorm": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _i32, _f32, _fp, C.c_size_t, C.c_void_p]),
     "edv_geglu": (C.c_int, [_fp, _fp, _i64, _i32, C.c_void_p]),
     "edv_rope_qk": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
+    "edv_trainer_loss_workspace": (C.c_size_t, [_i32, _i32, _i32]),
+    "edv_trainer_loss": (C.c_int, [C.c_void_p, _i32, _i32, _i32, C.c_void_p, _fp, C.c_void_p, _fp, C.c_size_t, C.c_void_p]),
     "edv_debug_fill_lds": (C.c_int, [C.c_float, C.c_void_p]),
     "edv_bilinear": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_void_p]),
     "edv_dot_channels": (C.c_int, [_fp, _fp, _fp, _fp, _i64, _i32, _i32, C.c_void_p]),
@@ -171,6 +173,23 @@ def check(status: int, what: str = "") -> None:
 def ptr(t) -> int:
     """Device pointer of a torch tensor (0 for None)."""
     return 0 if t is None else t.data_ptr()
+
+
+class TrainerLossInputs(C.Structure):
+    """edv_trainer_loss_inputs (include/endodav_hip.h)."""
+    _fields_ = [("color", C.c_void_p * 4), ("color_nb", C.c_void_p * 2), ("K", C.c_void_p), ("invK", C.c_void_p), ("T", C.c_void_p * 2),
+                ("refined", (C.c_void_p * 2) * 4), ("registration", (C.c_void_p * 2) * 4), ("transform", (C.c_void_p * 2) * 4), ("mask", C.c_void_p * 2),
+                ("position", (C.c_void_p * 2) * 4), ("disp", C.c_void_p * 4), ("disp_h", C.c_int32 * 4), ("disp_w", C.c_int32 * 4)]
+
+
+class TrainerLossWeights(C.Structure):
+    _fields_ = [("disparity_smoothness", C.c_float), ("transform_constraint", C.c_float), ("transform_smoothness", C.c_float), ("depth_reproj", C.c_float),
+                ("depth_flow", C.c_float), ("tune_temporal", C.c_int32), ("min_depth", C.c_float), ("max_depth", C.c_float)]
+
+
+class TrainerLossGrads(C.Structure):
+    _fields_ = [("disp", C.c_void_p * 4), ("refined", (C.c_void_p * 2) * 4), ("transform", (C.c_void_p * 2) * 4), ("K", C.c_void_p), ("invK", C.c_void_p),
+                ("T", C.c_void_p * 2)]
 
 
 def stream_ptr(device=None) -> int:

@@ -215,6 +215,42 @@ int edv_fold_lora(const float *W_dev, const float *A_dev, const float *B_dev, co
     return fold_lora(W_dev, A_dev, B_dev, U_dev, V_dev, scale, out_dev, nout, nin, r, (hipStream_t)stream);
 }
 
+size_t edv_trainer_loss_workspace(int32_t N, int32_t H, int32_t W) { return trainer_loss_workspace(N, H, W) * sizeof(float); }
+int edv_trainer_loss(const edv_trainer_loss_inputs *in, int32_t N, int32_t H, int32_t W, const edv_trainer_loss_weights *weights, float *losses_dev,
+                     const edv_trainer_loss_grads *grads, float *workspace_dev, size_t workspace_bytes, void *stream) {
+    EDV_CHECK(in && weights && grads, "null argument");
+    TrainerLossIn a{};
+    TrainerLossGrads g{};
+    for (int s = 0; s < 4; ++s) {
+        a.color[s] = in->color[s];
+        a.disp[s] = in->disp[s];
+        a.disp_h[s] = in->disp_h[s];
+        a.disp_w[s] = in->disp_w[s];
+        g.disp[s] = grads->disp[s];
+        for (int n = 0; n < 2; ++n) {
+            a.refined[s][n] = in->refined[s][n];
+            a.registration[s][n] = in->registration[s][n];
+            a.transform[s][n] = in->transform[s][n];
+            a.position[s][n] = in->position[s][n];
+            g.refined[s][n] = grads->refined[s][n];
+            g.transform[s][n] = grads->transform[s][n];
+        }
+    }
+    for (int n = 0; n < 2; ++n) {
+        a.color_nb[n] = in->color_nb[n];
+        a.T[n] = in->T[n];
+        a.mask[n] = in->mask[n];
+        g.T[n] = grads->T[n];
+    }
+    a.K = in->K;
+    a.invK = in->invK;
+    g.K = grads->K;
+    g.invK = grads->invK;
+    const TrainerLossW w{weights->disparity_smoothness, weights->transform_constraint, weights->transform_smoothness, weights->depth_reproj, weights->depth_flow,
+                         weights->tune_temporal, weights->min_depth, weights->max_depth};
+    return trainer_loss(a, N, H, W, w, losses_dev, g, workspace_dev, workspace_bytes / sizeof(float), (hipStream_t)stream);
+}
+
 size_t edv_photometric_loss_workspace(int32_t B, int32_t T, int32_t H, int32_t W) { return photometric_loss_workspace(B, T, H, W) * sizeof(float); }
 int edv_photometric_loss(const float *frames_dev, const float *const disp_dev[4], const int32_t disp_h[4], const int32_t disp_w[4], int32_t B, int32_t T, int32_t H,
                          int32_t W, const float *K_dev, const float *invK_dev, const float *Tprev_dev, const float *Tnext_dev, float min_depth, float max_depth,

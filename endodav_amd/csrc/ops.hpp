@@ -163,6 +163,30 @@ int dilate2(const float *dy, float *z, int F, int H, int W, int C, hipStream_t s
 int pack_conv3x3_bwd(const float *w, float *out, int Cout, int Cin, hipStream_t st);  // [Co,Ci,3,3] -> [Ci][3][3][Co], taps flipped
 
 // ------------------------------------------------------------------------------------------
+// the trainer's whole loss and every gradient its autograd reaches (loss_trainer.hip; include/endodav_hip.h documents the tensors)
+struct TrainerLossIn {
+    const float *color[4];
+    const float *color_nb[2];
+    const float *K, *invK;
+    const float *T[2];
+    const float *refined[4][2], *registration[4][2], *transform[4][2];
+    const float *mask[2];
+    const float *position[4][2];
+    const float *disp[4];
+    int disp_h[4], disp_w[4];
+};
+struct TrainerLossW {
+    float disparity_smoothness, transform_constraint, transform_smoothness, depth_reproj, depth_flow;
+    int tune_temporal;
+    float min_depth, max_depth;
+};
+struct TrainerLossGrads {
+    float *disp[4];
+    float *refined[4][2], *transform[4][2];
+    float *K, *invK, *T[2];
+};
+size_t trainer_loss_workspace(int N, int H, int W);  // floats
+int trainer_loss(const TrainerLossIn &in, int N, int H, int W, const TrainerLossW &w, float *losses, const TrainerLossGrads &g, float *ws, size_t ws_floats, hipStream_t st);
 // the fine-tune step's photometric loss + dL/d disp (loss.hip)
 size_t photometric_loss_workspace(int B, int T, int H, int W);  // floats
 int photometric_loss(const float *frames, const float *const disp[4], const int *dh, const int *dw, int B, int T, int H, int W, const float *K, const float *invK,

@@ -346,3 +346,100 @@ def photometric_loss_hip(disps: Dict[Tuple[str, int], torch.Tensor], frames: tor
     if not frames.is_cuda:
         raise RuntimeError("photometric_loss_hip runs on MI355X only; use photometric_loss for CPU tensors")
     return _PhotometricLossHip.apply(frames, K, inv_K, T_prev, T_next, int(clips), float(disparity_smoothness), *[disps[("disp", s)] for s in range(4)])
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# trainer_losses through libendodav_hip (csrc/loss_trainer.hip): every value of the trainer's `losses` dict and every gradient its autograd reaches
+# in one call.  `trainer_losses` above stays the definition (pinned by tests/golden/trainer_loss_kat.npz, captured from the reference's own methods).
+_TL_LEAVES = ([("disp", s) for s in range(4)] + ["K", "inv_K"] + [("cam_T_cam", 0, fid) for fid in FIDS] +
+              [("refined", s, fid) for s in range(4) for fid in FIDS] + [("transform", "high", s, fid) for s in range(4) for fid in FIDS])
+
+
+class _TrainerLossHip(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, inp, weights, *leaves):
+        import ctypes as C
+
+        from . import _lib
+
+        lib = _lib.load()
+        t = {k: v.detach().contiguous().float() for k, v in zip(_TL_LEAVES, leaves)}
+        frame = inp[("color", 0, 0)]
+        N, _, H, W = frame.shape
+        dev = frame.device
+        keep = []  # contiguous fp32 copies must outlive the launch
+
+        def ptr(x):
+            x = x.detach().contiguous().float()
+            keep.append(x)
+            return x.data_ptr()
+
+        a, g, w = _lib.TrainerLossInputs(), _lib.TrainerLossGrads(), _lib.TrainerLossWeights()
+        need = [v.requires_grad for v in leaves]
+        grads = {}
+
+        def gbuf(key):
+            if not need[_TL_LEAVES.index(key)]:
+                return None
+            grads[key] = torch.empty_like(t[key])
+            return grads[key].data_ptr()
+
+        want_flow = bool(weights.tune_temporal) and weights.depth_flow != 0.0
+        for s in range(4):
+            a.color[s] = ptr(inp[("color", 0, s)])
+            if tuple(inp[("color", 0, s)].shape[-2:]) != (H >> s, W >> s):
+                raise ValueError(f'("color", 0, {s}) must be {H >> s} x {W >> s} (height // 2**s, the dataset\'s pyramid)')
+            a.disp[s], a.disp_h[s], a.disp_w[s] = t[("disp", s)].data_ptr(), t[("disp", s)].shape[-2], t[("disp", s)].shape[-1]
+            grads[("disp", s)] = torch.empty_like(t[("disp", s)])
+            g.disp[s] = grads[("disp", s)].data_ptr()
+            for n, fid in enumerate(FIDS):
+                a.refined[s][n] = t[("refined", s, fid)].data_ptr()
+                a.transform[s][n] = t[("transform", "high", s, fid)].data_ptr()
+                a.registration[s][n] = ptr(inp[("registration", s, fid)])
+                a.position[s][n] = ptr(inp[("position", "high", s, fid)]) if want_flow else None
+                g.refined[s][n] = gbuf(("refined", s, fid))
+                g.transform[s][n] = gbuf(("transform", "high", s, fid))
+        for n, fid in enumerate(FIDS):
+            a.color_nb[n] = ptr(inp[("color", fid, 0)])
+            a.T[n] = t[("cam_T_cam", 0, fid)].data_ptr()
+            a.mask[n] = ptr(inp[("occu_mask_backward", 0, fid)])
+            g.T[n] = gbuf(("cam_T_cam", 0, fid))
+        a.K, a.invK = t["K"].data_ptr(), t["inv_K"].data_ptr()
+        g.K, g.invK = gbuf("K"), gbuf("inv_K")
+        w.disparity_smoothness, w.transform_constraint, w.transform_smoothness = weights.disparity_smoothness, weights.transform_constraint, weights.transform_smoothness
+        w.depth_reproj, w.depth_flow, w.tune_temporal = weights.depth_reproj, weights.depth_flow, int(bool(weights.tune_temporal))
+        w.min_depth, w.max_depth = weights.min_depth, weights.max_depth
+        with torch.cuda.device(dev):
+            nbytes = lib.edv_trainer_loss_workspace(N, H, W)
+            if nbytes == 0:
+                raise ValueError("the trainer loss needs frames of at least 16 x 16 pixels")
+            key = ("trainer", str(dev), N, H, W)
+            ws = _WS.get(key)
+            if ws is None or ws.numel() * 4 < nbytes:
+                ws = _WS[key] = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=dev)
+            values = torch.empty(29, dtype=torch.float32, device=dev)
+            _lib.check(lib.edv_trainer_loss(C.byref(a), N, H, W, C.byref(w), values.data_ptr(), C.byref(g), ws.data_ptr(), ws.numel() * 4,
+                                            C.c_void_p(_lib.stream_ptr(dev))), "edv_trainer_loss")
+        ctx.grads = [grads.get(k) for k in _TL_LEAVES]
+        ctx.mark_non_differentiable(values)
+        return values[28].clone(), values
+
+    @staticmethod
+    def backward(ctx, g, _):
+        return (None, None) + tuple(None if gr is None else g * gr for gr in ctx.grads)
+
+
+def trainer_losses_hip(disps: Dict[Tuple[str, int], torch.Tensor], inp: Dict, weights: TrainerLossWeights = TrainerLossWeights()) -> Dict[str, torch.Tensor]:
+    """``trainer_losses`` on MI355X through ``edv_trainer_loss``: the same dict; "loss" is differentiable with respect to the four disparity maps and to
+    whichever of K, inv_K, cam_T_cam, refined and transform_high require grad (the reference's autograd graph), the per-scale entries are values
+    (the trainer logs them with .item(), trainer_end_to_end_video.py:960-966)."""
+    if not inp[("color", 0, 0)].is_cuda:
+        raise RuntimeError("trainer_losses_hip runs on MI355X only; use trainer_losses for CPU tensors")
+    leaves = [disps[k] if isinstance(k, tuple) and k[0] == "disp" else inp[k] for k in _TL_LEAVES]
+    loss, values = _TrainerLossHip.apply(inp, weights, *leaves)
+    out = {"loss": loss}
+    names = ("", "loss_reprojection/", "loss_transform/", "loss_cvt/", "loss_smooth/", "loss_depth_reproj/", "loss_depth_flow/")
+    for s in range(4):
+        for k, nm in enumerate(names):
+            out[f"loss/{nm}{s}"] = values[s * 7 + k]
+    return out

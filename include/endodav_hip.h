@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EDV_ABI_VERSION 8 /* 8: edv_debug_fill_lds (test hook); 7: the split-bf16 experiment entry points left the library */
+#define EDV_ABI_VERSION 9 /* 9: edv_trainer_loss; 8: edv_debug_fill_lds (test hook); 7: the split-bf16 experiment entry points left the library */
 
 enum edv_lora_type { EDV_LORA_NONE = 0, EDV_LORA_LORA = 1, EDV_LORA_DVLORA = 2, EDV_LORA_SSB = 3, EDV_LORA_DASH = 4 };
 
@@ -291,6 +291,45 @@ size_t edv_photometric_loss_workspace(int32_t B, int32_t T, int32_t H, int32_t W
 int edv_photometric_loss(const float *frames_dev, const float *const disp_dev[4], const int32_t disp_h[4], const int32_t disp_w[4], int32_t B, int32_t T, int32_t H,
                          int32_t W, const float *K_dev, const float *invK_dev, const float *Tprev_dev, const float *Tnext_dev, float min_depth, float max_depth,
                          float disparity_smoothness, float *loss_dev, float *const grad_disp_dev[4], float *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* ---- the trainer's whole loss (round 3): generate_images_pred + compute_losses of trainer_end_to_end_video.py:808-971 with the side networks'
+ * outputs as inputs, and every gradient the reference's autograd reaches.  N = B*T flattened frames (trainer :406-409), frame size H x W.
+ *   color[s]            inputs[("color", 0, s)]            [N, 3, H >> s, W >> s]   (s = 0: the frame)
+ *   color_nb[0 / 1]     inputs[("color", -1 / +1, 0)]      [N, 3, H, W]
+ *   K, invK             [N, 4, 4] row-major (inputs[("K", 0)] or, with learn_intrinsics, outputs[("K", 0)]);  T[0 / 1] = outputs[("cam_T_cam", 0, -1 / +1)]
+ *   refined[s][n], registration[s][n], transform[s][n] = outputs[("refined" | "registration", s, fid)], outputs[("transform", "high", s, fid)]   [N, 3, H, W]
+ *   mask[n]             outputs[("occu_mask_backward", 0, fid)]   [N, 1, H, W];   position[s][n] = outputs[("position", "high", s, fid)] [N, 2, H, W]
+ *                       (position may be NULL when depth_flow is 0 or tune_temporal is off)
+ *   disp[s]             outputs[("disp", s)]   [N, 1, disp_h[s], disp_w[s]]
+ * losses_dev receives 29 floats: for s = 0..3 {loss/s, loss_reprojection, loss_transform, loss_cvt, loss_smooth, loss_depth_reproj, loss_depth_flow}
+ * (the trainer's per-scale entries, :960-966), then losses["loss"] (:968).  Gradients of losses["loss"]: grads->disp[s] are required; refined /
+ * transform / K / invK / T are optional (NULL = not wanted); registration and the mask are detached in the reference.  Deterministic except for the
+ * gradient the two depth-consistency terms scatter into the sampled depth map (float atomics, as ATen's grid_sampler backward); with the options'
+ * defaults (depth_reproj = depth_flow = 0) no atomic runs.  H, W >= 16. */
+typedef struct {
+    const float *color[4];
+    const float *color_nb[2];
+    const float *K, *invK;
+    const float *T[2];
+    const float *refined[4][2], *registration[4][2], *transform[4][2];
+    const float *mask[2];
+    const float *position[4][2];
+    const float *disp[4];
+    int32_t disp_h[4], disp_w[4];
+} edv_trainer_loss_inputs;
+typedef struct {
+    float disparity_smoothness, transform_constraint, transform_smoothness, depth_reproj, depth_flow; /* options.py:136-159 */
+    int32_t tune_temporal;                                                                              /* trainer :951 temporal_weight */
+    float min_depth, max_depth;
+} edv_trainer_loss_weights;
+typedef struct {
+    float *disp[4];
+    float *refined[4][2], *transform[4][2];
+    float *K, *invK, *T[2];
+} edv_trainer_loss_grads;
+size_t edv_trainer_loss_workspace(int32_t N, int32_t H, int32_t W); /* bytes */
+int edv_trainer_loss(const edv_trainer_loss_inputs *in, int32_t N, int32_t H, int32_t W, const edv_trainer_loss_weights *weights, float *losses_dev,
+                     const edv_trainer_loss_grads *grads, float *workspace_dev, size_t workspace_bytes, void *stream);
 
 /* ---- backward kernels (input gradients of the frozen operators, gradients of the LoRA factors): input gradients of the frozen operators and the gradients of the
  * LoRA factors, the only trainable tensors (endodav/layers.py:5-34).  Same layouts as the forward kernels. ---- */

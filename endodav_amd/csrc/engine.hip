@@ -2025,9 +2025,11 @@ int edv_forward(edv_ctx *ctx, const float *x_dev, int32_t B, int32_t T, int32_t 
     EDV_CHECK(B > 0 && T > 0 && H > 1 && W > 1, "empty clip");
     // motion_module.py:197: the position table is sliced to T -> size mismatch beyond num_frames
     EDV_CHECK(T <= ctx->cfg.num_frames, "T exceeds num_frames (temporal_max_len)");
-    // narrower than the reference, which takes any T <= num_frames: the temporal-attention kernels hold one clip's T x T scores per
-    // pixel on chip and are built for T <= 32 = the reference's own INFER_LEN and num_frames default (endodav.py:47, :62)
-    EDV_CHECK(T <= 32, "T > 32 frames per clip is not built (the reference's window length and num_frames default are 32)");
+    // The reference takes any T <= num_frames (dpt_temporal.py:35-40, motion_module.py:180-198).  The temporal-attention kernels hold one pixel's
+    // T x T scores on chip: the forward is built up to T = 128 (round 3), the backward up to 32 = the reference's own window length and
+    // num_frames default (endodav.py:47, :62; its training scripts use T = 16)
+    EDV_CHECK(T <= 128, "T > 128 frames per clip is not built");
+    EDV_CHECK(!ctx->train || T <= 32, "a training forward with T > 32 frames per clip is not built (the backward of the temporal attention stops at 32)");
 
     EDV_CHECK((long long)B * T <= 65535, "too many frames in one call");
     for (int k = 0; k < 4; ++k) EDV_CHECK(disp_dev[k], "null output");

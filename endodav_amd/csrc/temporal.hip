@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void rope_qk_kernel(float *__restrict__ qkv, c
 int attn_temporal(const float *qkv, float *out, int B, int T, int P, int C, int heads, hipStream_t st) {
     EDV_CHECK(qkv && out, "null operand");
     EDV_CHECK(B > 0 && T > 0 && P > 0 && C > 0 && heads > 0, "empty problem");
-    EDV_CHECK(T <= 32, "T > 32 is not supported by the temporal attention kernel");
+    EDV_CHECK(T <= 128, "T > 128 frames per clip is not built (temporal attention keeps a pixel's T x T scores on chip)");
     EDV_CHECK(C % heads == 0 && (C / heads) % 4 == 0, "head dim must be a multiple of 4");
     const long long total = (long long)B * T * P * heads;
     const long long blocks = (total + 255) / 256;
@@ -256,7 +256,9 @@ int attn_temporal(const float *qkv, float *out, int B, int T, int P, int C, int 
     const int d = C / heads;
     int HG = heads;  // heads per workgroup: as many as fit 256 threads and 64 KB of LDS
     while (HG > 1 && ((long long)T * HG > 256 || (size_t)T * 3 * HG * d * sizeof(float) > 64 * 1024 || heads % HG != 0)) --HG;
-    const bool pixel_fits = (long long)T * HG <= 256 && (size_t)T * 3 * HG * d * sizeof(float) <= 64 * 1024 && (long long)B * P * (heads / HG) < (1ll << 31);
+    // one head of a long clip may need more than 64 KB (T = 100 at d = 128: 150 KB): the CU has 160
+    const size_t lds_cap = (T > 32 && HG == 1) ? 160 * 1024 : 64 * 1024;
+    const bool pixel_fits = (long long)T * HG <= 256 && (size_t)T * 3 * HG * d * sizeof(float) <= lds_cap && (long long)B * P * (heads / HG) < (1ll << 31);
     if (!per_query && pixel_fits && (T > 8 || d >= 24)) {
         const dim3 g3((unsigned)((long long)B * P * (heads / HG)));
         const dim3 b3((unsigned)(((T * HG + 63) / 64) * 64));
@@ -265,8 +267,20 @@ int attn_temporal(const float *qkv, float *out, int B, int T, int P, int C, int 
             hipLaunchKernelGGL(attn_temporal_pixel_kernel<8>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
         else if (T <= 16)
             hipLaunchKernelGGL(attn_temporal_pixel_kernel<16>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
-        else
+        else if (T <= 32)
             hipLaunchKernelGGL(attn_temporal_pixel_kernel<32>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
+        else if (lds > 64 * 1024 && T <= 64) {
+            EDV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_temporal_pixel_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+            hipLaunchKernelGGL(attn_temporal_pixel_kernel<64>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
+        } else if (lds > 64 * 1024) {
+            EDV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_temporal_pixel_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+            hipLaunchKernelGGL(attn_temporal_pixel_kernel<128>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
+        } else if (T <= 64)  // num_frames > 32 (dpt_temporal.py:35-40 takes any; the reference's scripts keep the default 32)
+            hipLaunchKernelGGL(attn_temporal_pixel_kernel<64>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
+        else
+            hipLaunchKernelGGL(attn_temporal_pixel_kernel<128>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
+    } else if (T > 32) {
+        EDV_CHECK(false, "temporal attention over more than 32 frames: one head's q|k|v of a pixel (T x 3 x C/8 floats) must fit the 160 KB of LDS");
     } else if (T <= 8 && !per_query) {
         const long long tot = (long long)B * P * heads;
         const dim3 g2((unsigned)((tot + 255) / 256));

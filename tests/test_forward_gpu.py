@@ -316,6 +316,10 @@ def test_errors_are_loud(cuda):
             model(torch.rand(1, 33, 3, 42, 56, device=cuda))
     with pytest.raises(KeyError):
         endodav_amd.endodav(encoder="vitx")
+    long_model = endodav_amd.endodav(**{**kwargs, "num_frames": 48}).to(cuda).train()  # num_frames > 32: inference is built (goldens micro_t48 / micro_t80),
+    endodav_amd.mark_only_part_as_trainable(long_model, warm_up=True)                     # a training forward beyond 32 frames is refused, not mis-differentiated
+    with pytest.raises(RuntimeError, match="32"):
+        long_model(torch.rand(1, 40, 3, 42, 56, device=cuda))
     model.get_parameter("head.scratch.layer1_rn.weight").requires_grad = True
     with pytest.raises(NotImplementedError):  # a trainable tensor the HIP backward has no gradient for is refused, not silently frozen
         model(x)

@@ -181,7 +181,7 @@ int edv_debug_fill_lds(float value, void *stream) {
     EDV_HIP(hipGetDevice(&dev));
     EDV_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
     EDV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(edv::fill_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(edv::fill_lds_kernel, dim3((unsigned)(8 * cus)), dim3(256), 160 * 1024, (hipStream_t)stream, value, (float *)nullptr);
+    EDV_LAUNCH(edv::fill_lds_kernel, dim3((unsigned)(8 * cus)), dim3(256), 160 * 1024, (hipStream_t)stream, value, (float *)nullptr);
     EDV_LAUNCH_OK();
     return 0;
 }

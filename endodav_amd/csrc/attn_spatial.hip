@@ -636,19 +636,19 @@ int attn_spatial(const float *qkv, float *out, int F, int N, int heads, float *w
     EDV_CHECK(p.ws_floats == 0 || (ws && ws_floats >= p.ws_floats && (uintptr_t)ws % 16 == 0), "attention workspace too small (attn_spatial_workspace)");
     dim3 grid((unsigned)p.grid);
     if (p.pipe)
-        hipLaunchKernelGGL((attn_lean_kernel), grid, dim3(256), 0, st, qkv, out, ws, lse, N, heads, p.whole_rounds, p.units, p.chunk);
+        EDV_LAUNCH((attn_lean_kernel), grid, dim3(256), 0, st, qkv, out, ws, lse, N, heads, p.whole_rounds, p.units, p.chunk);
     else if (p.nw == 4 && p.kt == 32)
-        hipLaunchKernelGGL((attn_spatial_kernel<4, 32>), grid, dim3(256), 0, st, qkv, out, ws, lse, N, heads, p.whole_rounds, p.units, p.chunk);
+        EDV_LAUNCH((attn_spatial_kernel<4, 32>), grid, dim3(256), 0, st, qkv, out, ws, lse, N, heads, p.whole_rounds, p.units, p.chunk);
     else if (p.nw == 4)
-        hipLaunchKernelGGL((attn_spatial_kernel<4, 64>), grid, dim3(256), 0, st, qkv, out, ws, lse, N, heads, p.whole_rounds, p.units, p.chunk);
+        EDV_LAUNCH((attn_spatial_kernel<4, 64>), grid, dim3(256), 0, st, qkv, out, ws, lse, N, heads, p.whole_rounds, p.units, p.chunk);
     else if (p.nw == 2)
-        hipLaunchKernelGGL((attn_spatial_kernel<2, 32>), grid, dim3(128), 0, st, qkv, out, ws, lse, N, heads, p.whole_rounds, p.units, p.chunk);
+        EDV_LAUNCH((attn_spatial_kernel<2, 32>), grid, dim3(128), 0, st, qkv, out, ws, lse, N, heads, p.whole_rounds, p.units, p.chunk);
     else
-        hipLaunchKernelGGL((attn_spatial_kernel<1, 32>), grid, dim3(64), 0, st, qkv, out, ws, lse, N, heads, p.whole_rounds, p.units, p.chunk);
+        EDV_LAUNCH((attn_spatial_kernel<1, 32>), grid, dim3(64), 0, st, qkv, out, ws, lse, N, heads, p.whole_rounds, p.units, p.chunk);
     EDV_LAUNCH_OK();
     if (p.leftover) {
         const int QB = p.nw * 32;
-        hipLaunchKernelGGL(attn_combine_kernel, dim3((unsigned)p.leftover, (unsigned)(QB / 16)), dim3(256), 0, st, ws, out, lse, N, heads, QB, p.ntiles,
+        EDV_LAUNCH(attn_combine_kernel, dim3((unsigned)p.leftover, (unsigned)(QB / 16)), dim3(256), 0, st, ws, out, lse, N, heads, QB, p.ntiles,
                            p.whole_rounds * p.grid, p.units, p.chunk);
         EDV_LAUNCH_OK();
     }

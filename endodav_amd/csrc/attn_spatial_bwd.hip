@@ -367,7 +367,7 @@ int attn_spatial_bwd(const float *qkv, const float *out, const float *dout, cons
     EDV_CHECK(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 16 == 0) && ((uintptr_t)dout % 16 == 0) && ((uintptr_t)dqkv % 16 == 0), "16-byte alignment");
     const long long pairs = (long long)F * N * heads;
     EDV_CHECK((pairs * 16 + 255) / 256 < (1ll << 31), "grid");
-    hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((pairs * 16 + 255) / 256)), dim3(256), 0, st, dout, out, delta, F, N, heads);
+    EDV_LAUNCH(attn_delta_kernel, dim3((unsigned)((pairs * 16 + 255) / 256)), dim3(256), 0, st, dout, out, delta, F, N, heads);
     EDV_LAUNCH_OK();
     const long long ntasks = (long long)F * heads * ((N + 127) / 128);
     EDV_CHECK(ntasks < (1ll << 31), "grid");
@@ -377,19 +377,19 @@ int attn_spatial_bwd(const float *qkv, const float *out, const float *dout, cons
     const BwdPlan pk = make_bwd_plan(ntasks, N, bwd_slots<MODE_DKV, 4>(), 128, 2 * HD, bwd_plain());
     const size_t need = pq.ws_floats > pk.ws_floats ? pq.ws_floats : pk.ws_floats;
     EDV_CHECK(need == 0 || (ws && ws_floats >= need && (uintptr_t)ws % 16 == 0), "attention backward workspace too small (attn_spatial_bwd_workspace)");
-    hipLaunchKernelGGL((attn_spatial_bwd_kernel<MODE_DQ, 4>), dim3((unsigned)pq.grid), dim3(256), 0, st, qkv, dout, lse, delta, dqkv, ws, N, heads,
+    EDV_LAUNCH((attn_spatial_bwd_kernel<MODE_DQ, 4>), dim3((unsigned)pq.grid), dim3(256), 0, st, qkv, dout, lse, delta, dqkv, ws, N, heads,
                        pq.whole_rounds, pq.units, pq.chunk);
     EDV_LAUNCH_OK();
     if (pq.leftover) {
-        hipLaunchKernelGGL(attn_bwd_combine_kernel<MODE_DQ>, dim3((unsigned)pq.leftover, (128 * HD / 4 + 255) / 256), dim3(256), 0, st, ws, dqkv, N, heads, 128,
+        EDV_LAUNCH(attn_bwd_combine_kernel<MODE_DQ>, dim3((unsigned)pq.leftover, (128 * HD / 4 + 255) / 256), dim3(256), 0, st, ws, dqkv, N, heads, 128,
                            pq.ntiles, pq.whole_rounds * pq.grid, pq.chunk);
         EDV_LAUNCH_OK();
     }
-    hipLaunchKernelGGL((attn_spatial_bwd_kernel<MODE_DKV, 4>), dim3((unsigned)pk.grid), dim3(256), 0, st, qkv, dout, lse, delta, dqkv, ws, N, heads,
+    EDV_LAUNCH((attn_spatial_bwd_kernel<MODE_DKV, 4>), dim3((unsigned)pk.grid), dim3(256), 0, st, qkv, dout, lse, delta, dqkv, ws, N, heads,
                        pk.whole_rounds, pk.units, pk.chunk);
     EDV_LAUNCH_OK();
     if (pk.leftover) {
-        hipLaunchKernelGGL(attn_bwd_combine_kernel<MODE_DKV>, dim3((unsigned)pk.leftover, (128 * 2 * HD / 4 + 255) / 256), dim3(256), 0, st, ws, dqkv, N, heads,
+        EDV_LAUNCH(attn_bwd_combine_kernel<MODE_DKV>, dim3((unsigned)pk.leftover, (128 * 2 * HD / 4 + 255) / 256), dim3(256), 0, st, ws, dqkv, N, heads,
                            128, pk.ntiles, pk.whole_rounds * pk.grid, pk.chunk);
         EDV_LAUNCH_OK();
     }

@@ -728,7 +728,7 @@ int layernorm_bwd(const float *x, RowMap xmap, const float *w, const float *dy, 
     EDV_CHECK(rows > 0 && dim % 4 == 0 && dim <= 256 * LNB_MAXV, "dim must be a multiple of 4 and <= 1024");
     const long long blocks = (rows + 3) / 4;
     EDV_CHECK(blocks < (1ll << 31), "grid");
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, xmap, w, dy, dymap, dx, dxmap, rows, dim, eps, accumulate ? 1 : 0);
+    EDV_LAUNCH(layernorm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, xmap, w, dy, dymap, dx, dxmap, rows, dim, eps, accumulate ? 1 : 0);
     EDV_LAUNCH_OK();
     return 0;
 }
@@ -736,14 +736,14 @@ int layernorm_bwd(const float *x, RowMap xmap, const float *w, const float *dy, 
 int ew_bwd(const float *d, const float *src, const float *add, float *out, long long n, int mode, hipStream_t st) {
     EDV_CHECK(d && out && n > 0 && n % 4 == 0, "shape");
     EDV_CHECK(mode >= 0 && mode <= 3 && (mode == 0 || mode == 3 || src), "mode");
-    hipLaunchKernelGGL(ew_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, st, d, src, add, out, n / 4, mode);
+    EDV_LAUNCH(ew_bwd_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, st, d, src, add, out, n / 4, mode);
     EDV_LAUNCH_OK();
     return 0;
 }
 
 int sigmoid_bwd(const float *g, const float *s, float *out, long long n, hipStream_t st) {
     EDV_CHECK(g && s && out && n > 0, "shape");
-    hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, g, s, out, n);
+    EDV_LAUNCH(sigmoid_bwd_kernel, dim3(ew_blocks(n)), dim3(256), 0, st, g, s, out, n);
     EDV_LAUNCH_OK();
     return 0;
 }
@@ -751,14 +751,14 @@ int sigmoid_bwd(const float *g, const float *s, float *out, long long n, hipStre
 int geglu_bwd(const float *x, const float *dy, float *dx, long long M, int inner, hipStream_t st) {
     EDV_CHECK(x && dy && dx && M > 0 && inner > 0 && inner % 4 == 0, "shape");
     const long long total4 = M * (inner / 4);
-    hipLaunchKernelGGL(geglu_bwd_kernel, dim3(ew_blocks(total4)), dim3(256), 0, st, x, dy, dx, total4, inner / 4);
+    EDV_LAUNCH(geglu_bwd_kernel, dim3(ew_blocks(total4)), dim3(256), 0, st, x, dy, dx, total4, inner / 4);
     EDV_LAUNCH_OK();
     return 0;
 }
 
 int transpose_scale(const float *W, int ldw, const float *gamma, float *Wt, int N, int K, hipStream_t st) {
     EDV_CHECK(W && Wt && N > 0 && K > 0 && ldw >= K, "shape");
-    hipLaunchKernelGGL(transpose_scale_kernel, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, st, W, gamma, Wt, N, K, ldw);
+    EDV_LAUNCH(transpose_scale_kernel, dim3((K + 31) / 32, (N + 31) / 32), dim3(256), 0, st, W, gamma, Wt, N, K, ldw);
     EDV_LAUNCH_OK();
     return 0;
 }
@@ -770,10 +770,10 @@ int skinny_xwt(const float *X, long long M, int K, int ldx, const float *Wr, int
     EDV_CHECK(blocks < (1ll << 31), "grid");
     dim3 grid((unsigned)blocks), block(256);
     switch (r) {
-        case 1: hipLaunchKernelGGL(skinny_xwt_kernel<1>, grid, block, 0, st, X, M, K, ldx, Wr, T); break;
-        case 2: hipLaunchKernelGGL(skinny_xwt_kernel<2>, grid, block, 0, st, X, M, K, ldx, Wr, T); break;
-        case 4: hipLaunchKernelGGL(skinny_xwt_kernel<4>, grid, block, 0, st, X, M, K, ldx, Wr, T); break;
-        default: hipLaunchKernelGGL(skinny_xwt_kernel<8>, grid, block, 0, st, X, M, K, ldx, Wr, T); break;
+        case 1: EDV_LAUNCH(skinny_xwt_kernel<1>, grid, block, 0, st, X, M, K, ldx, Wr, T); break;
+        case 2: EDV_LAUNCH(skinny_xwt_kernel<2>, grid, block, 0, st, X, M, K, ldx, Wr, T); break;
+        case 4: EDV_LAUNCH(skinny_xwt_kernel<4>, grid, block, 0, st, X, M, K, ldx, Wr, T); break;
+        default: EDV_LAUNCH(skinny_xwt_kernel<8>, grid, block, 0, st, X, M, K, ldx, Wr, T); break;
     }
     EDV_LAUNCH_OK();
     return 0;
@@ -788,13 +788,13 @@ int tall_tn(const float *Y, int ldy, const float *T, long long M, int N, int r, 
     const int splits = (int)((M + rows_per_split - 1) / rows_per_split);
     dim3 grid((N + 63) / 64, splits), block(256);
     switch (r) {
-        case 1: hipLaunchKernelGGL(tall_tn_partial_kernel<1>, grid, block, 0, st, Y, ldy, T, M, N, part, rows_per_split); break;
-        case 2: hipLaunchKernelGGL(tall_tn_partial_kernel<2>, grid, block, 0, st, Y, ldy, T, M, N, part, rows_per_split); break;
-        case 4: hipLaunchKernelGGL(tall_tn_partial_kernel<4>, grid, block, 0, st, Y, ldy, T, M, N, part, rows_per_split); break;
-        default: hipLaunchKernelGGL(tall_tn_partial_kernel<8>, grid, block, 0, st, Y, ldy, T, M, N, part, rows_per_split); break;
+        case 1: EDV_LAUNCH(tall_tn_partial_kernel<1>, grid, block, 0, st, Y, ldy, T, M, N, part, rows_per_split); break;
+        case 2: EDV_LAUNCH(tall_tn_partial_kernel<2>, grid, block, 0, st, Y, ldy, T, M, N, part, rows_per_split); break;
+        case 4: EDV_LAUNCH(tall_tn_partial_kernel<4>, grid, block, 0, st, Y, ldy, T, M, N, part, rows_per_split); break;
+        default: EDV_LAUNCH(tall_tn_partial_kernel<8>, grid, block, 0, st, Y, ldy, T, M, N, part, rows_per_split); break;
     }
     EDV_LAUNCH_OK();
-    hipLaunchKernelGGL(tall_tn_reduce_kernel, dim3((N * r + 31) / 32), dim3(256), 0, st, part, splits, N, r, scale, rowscale, out);
+    EDV_LAUNCH(tall_tn_reduce_kernel, dim3((N * r + 31) / 32), dim3(256), 0, st, part, splits, N, r, scale, rowscale, out);
     EDV_LAUNCH_OK();
     return 0;
 }
@@ -805,10 +805,10 @@ int lora_grad_finalize(const float *dBp, const float *dApT, const float *A, cons
     EDV_CHECK((U == nullptr) == (V == nullptr), "U and V come together");
     EDV_CHECK(!U || (A && Bm), "dvlora needs A and B");
     const int n = (nout > nin ? nout : nin) * r;
-    hipLaunchKernelGGL(lora_grad_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dBp, dApT, A, Bm, U, V, dA, dB, dV, nout, nin, r);
+    EDV_LAUNCH(lora_grad_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, st, dBp, dApT, A, Bm, U, V, dA, dB, dV, nout, nin, r);
     EDV_LAUNCH_OK();
     if (U && dU) {
-        hipLaunchKernelGGL(lora_grad_u_kernel, dim3(r), dim3(256), 0, st, dApT, A, dU, nin, r);
+        EDV_LAUNCH(lora_grad_u_kernel, dim3(r), dim3(256), 0, st, dApT, A, dU, nin, r);
         EDV_LAUNCH_OK();
     }
     return 0;
@@ -829,7 +829,7 @@ int lora_grads(const float *X, int ldx, const float *G, int ldg, long long M, in
     float *part = BgT + (size_t)r * nout;
     float *dBp = part + tall_tn_workspace(nin > nout ? nin : nout, r), *dApT = dBp + (size_t)r * nout;
     const int nf = r * (nin > nout ? nin : nout);
-    hipLaunchKernelGGL(lora_factors_kernel, dim3((nf + 255) / 256), dim3(256), 0, st, A, Bm, U, V, gamma, Aeff, BgT, nout, nin, r);
+    EDV_LAUNCH(lora_factors_kernel, dim3((nf + 255) / 256), dim3(256), 0, st, A, Bm, U, V, gamma, Aeff, BgT, nout, nin, r);
     EDV_LAUNCH_OK();
     EDV_TRY(skinny_xwt(X, M, nin, ldx, Aeff, r, t, st));
     EDV_TRY(skinny_xwt(G, M, nout, ldg, BgT, r, u, st));
@@ -841,7 +841,7 @@ int lora_grads(const float *X, int ldx, const float *G, int ldg, long long M, in
 int ssb_prep(const float *W, const float *a, const float *b, const float *gamma, float *Wa, float *gb, int nout, int nin, hipStream_t st) {
     EDV_CHECK(W && a && b && Wa && gb && nout > 0 && nin > 0, "shape");
     const long long n = (long long)nout * nin;
-    hipLaunchKernelGGL(ssb_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, a, b, gamma, Wa, gb, nout, nin);
+    EDV_LAUNCH(ssb_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, a, b, gamma, Wa, gb, nout, nin);
     EDV_LAUNCH_OK();
     return 0;
 }
@@ -851,9 +851,9 @@ int col_dot(const float *P, const float *Q, long long M, int N, const float *sca
     EDV_CHECK(P && part && out && M > 0 && N > 0, "shape");  // Q may be null: plain column sums
     const int rows_per_split = (int)((M + TALL_SPLITS - 1) / TALL_SPLITS);
     const int splits = (int)((M + rows_per_split - 1) / rows_per_split);
-    hipLaunchKernelGGL(col_dot_partial_kernel, dim3((N + 63) / 64, splits), dim3(256), 0, st, P, Q, M, N, part, rows_per_split);
+    EDV_LAUNCH(col_dot_partial_kernel, dim3((N + 63) / 64, splits), dim3(256), 0, st, P, Q, M, N, part, rows_per_split);
     EDV_LAUNCH_OK();
-    hipLaunchKernelGGL(tall_tn_reduce_kernel, dim3((N + 31) / 32), dim3(256), 0, st, part, splits, N, 1, 1.0f, scale, out);
+    EDV_LAUNCH(tall_tn_reduce_kernel, dim3((N + 31) / 32), dim3(256), 0, st, part, splits, N, 1, 1.0f, scale, out);
     EDV_LAUNCH_OK();
     return 0;
 }
@@ -864,11 +864,11 @@ int bilinear_bwd(const float *dy, float *dx, int F, int ih, int iw, int C, int o
     if (C % 4 == 0) {
         const long long total = (long long)F * ih * iw * (C / 4);
         EDV_CHECK((total + 255) / 256 < (1ll << 31), "grid");
-        hipLaunchKernelGGL(bilinear_bwd_kernel<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, dx, F, ih, iw, C, oh, ow, ry, rx, accumulate ? 1 : 0);
+        EDV_LAUNCH(bilinear_bwd_kernel<4>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, dx, F, ih, iw, C, oh, ow, ry, rx, accumulate ? 1 : 0);
     } else {
         const long long total = (long long)F * ih * iw * C;
         EDV_CHECK((total + 255) / 256 < (1ll << 31), "grid");
-        hipLaunchKernelGGL(bilinear_bwd_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, dx, F, ih, iw, C, oh, ow, ry, rx, accumulate ? 1 : 0);
+        EDV_LAUNCH(bilinear_bwd_kernel<1>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, dx, F, ih, iw, C, oh, ow, ry, rx, accumulate ? 1 : 0);
     }
     EDV_LAUNCH_OK();
     return 0;
@@ -878,7 +878,7 @@ int dot_channels_bwd(const float *g, const float *disp, const float *w, const fl
                      hipStream_t st) {
     EDV_CHECK(g && disp && w && o2 && d_o2 && npix > 0 && C % 4 == 0, "shape");
     EDV_CHECK(mode >= 0 && mode <= 2, "mode: 0 ReLU, 1 sigmoid(z), 2 sigmoid(-z)");
-    hipLaunchKernelGGL(dot_channels_bwd_kernel, dim3(ew_blocks(npix * (C / 4))), dim3(256), 0, st, g, disp, w, o2, d_o2, gz_out, npix, C, mode);
+    EDV_LAUNCH(dot_channels_bwd_kernel, dim3(ew_blocks(npix * (C / 4))), dim3(256), 0, st, g, disp, w, o2, d_o2, gz_out, npix, C, mode);
     EDV_LAUNCH_OK();
     return 0;
 }
@@ -887,10 +887,10 @@ int groupnorm_bwd(const float *x, const float *stats, const float *w, const floa
                   hipStream_t st) {
     EDV_CHECK(x && stats && w && dy && sums && dx, "null operand");
     EDV_CHECK(F > 0 && F <= 65535 && P > 0 && C > 0 && groups > 0 && C % groups == 0 && C % 4 == 0, "shape");
-    hipLaunchKernelGGL(groupnorm_bwd_sums_kernel, dim3(groups, F), dim3(256), 0, st, x, stats, w, dy, sums, P, C, groups);
+    EDV_LAUNCH(groupnorm_bwd_sums_kernel, dim3(groups, F), dim3(256), 0, st, x, stats, w, dy, sums, P, C, groups);
     EDV_LAUNCH_OK();
     const long long total4 = (long long)F * P * C / 4;
-    hipLaunchKernelGGL(groupnorm_bwd_apply_kernel, dim3(ew_blocks(total4)), dim3(256), 0, st, x, stats, w, dy, sums, dx, total4, P, C, groups, accumulate ? 1 : 0);
+    EDV_LAUNCH(groupnorm_bwd_apply_kernel, dim3(ew_blocks(total4)), dim3(256), 0, st, x, stats, w, dy, sums, dx, total4, P, C, groups, accumulate ? 1 : 0);
     EDV_LAUNCH_OK();
     return 0;
 }
@@ -915,17 +915,17 @@ int attn_temporal_bwd(const float *qkv, const float *dout, float *dqkv, int B, i
     if (pixel_fits && !per_thread) {
         const dim3 g3((unsigned)((long long)B * P * (heads / HG))), b3((unsigned)(((T * HG + 63) / 64) * 64));
         if (TM == 8)
-            hipLaunchKernelGGL(attn_temporal_bwd_pixel_kernel<8>, g3, b3, lds_of(HG), st, qkv, dout, dqkv, T, P, C, heads, HG, scale);
+            EDV_LAUNCH(attn_temporal_bwd_pixel_kernel<8>, g3, b3, lds_of(HG), st, qkv, dout, dqkv, T, P, C, heads, HG, scale);
         else if (TM == 16)
-            hipLaunchKernelGGL(attn_temporal_bwd_pixel_kernel<16>, g3, b3, lds_of(HG), st, qkv, dout, dqkv, T, P, C, heads, HG, scale);
+            EDV_LAUNCH(attn_temporal_bwd_pixel_kernel<16>, g3, b3, lds_of(HG), st, qkv, dout, dqkv, T, P, C, heads, HG, scale);
         else
-            hipLaunchKernelGGL(attn_temporal_bwd_pixel_kernel<32>, g3, b3, lds_of(HG), st, qkv, dout, dqkv, T, P, C, heads, HG, scale);
+            EDV_LAUNCH(attn_temporal_bwd_pixel_kernel<32>, g3, b3, lds_of(HG), st, qkv, dout, dqkv, T, P, C, heads, HG, scale);
     } else if (T <= 8)
-        hipLaunchKernelGGL(attn_temporal_bwd_kernel<8>, grid, block, 0, st, qkv, dout, dqkv, B, T, P, C, heads, scale);
+        EDV_LAUNCH(attn_temporal_bwd_kernel<8>, grid, block, 0, st, qkv, dout, dqkv, B, T, P, C, heads, scale);
     else if (T <= 16)
-        hipLaunchKernelGGL(attn_temporal_bwd_kernel<16>, grid, block, 0, st, qkv, dout, dqkv, B, T, P, C, heads, scale);
+        EDV_LAUNCH(attn_temporal_bwd_kernel<16>, grid, block, 0, st, qkv, dout, dqkv, B, T, P, C, heads, scale);
     else
-        hipLaunchKernelGGL(attn_temporal_bwd_kernel<32>, grid, block, 0, st, qkv, dout, dqkv, B, T, P, C, heads, scale);
+        EDV_LAUNCH(attn_temporal_bwd_kernel<32>, grid, block, 0, st, qkv, dout, dqkv, B, T, P, C, heads, scale);
     EDV_LAUNCH_OK();
     return 0;
 }
@@ -933,7 +933,7 @@ int attn_temporal_bwd(const float *qkv, const float *dout, float *dqkv, int B, i
 int pixel_unshuffle(const float *dy, float *A, int F, int h, int w, int C, int s, hipStream_t st) {
     EDV_CHECK(dy && A && F > 0 && h > 0 && w > 0 && C % 4 == 0 && s > 0, "shape");
     const long long total = (long long)F * h * w * s * s * (C / 4);
-    hipLaunchKernelGGL(pixel_unshuffle_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, dy, A, F, h, w, C, s);
+    EDV_LAUNCH(pixel_unshuffle_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, dy, A, F, h, w, C, s);
     EDV_LAUNCH_OK();
     return 0;
 }
@@ -943,7 +943,7 @@ int conv3x3_s2_bwd(const float *dy, const float *wpacked, float *dx, int F, int 
     const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
     const long long total = (long long)F * H * W * Cin;
     EDV_CHECK((total + 255) / 256 < (1ll << 31), "grid");
-    hipLaunchKernelGGL(conv3x3_s2_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, wpacked, dx, F, H, W, Cin, Cout, OH, OW);
+    EDV_LAUNCH(conv3x3_s2_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dy, wpacked, dx, F, H, W, Cin, Cout, OH, OW);
     EDV_LAUNCH_OK();
     return 0;
 }
@@ -952,7 +952,7 @@ int dilate2(const float *dy, float *z, int F, int H, int W, int C, hipStream_t s
     EDV_CHECK(dy && z && F > 0 && H > 0 && W > 0 && C % 4 == 0, "shape");
     const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
     const long long total = (long long)F * H * W * (C / 4);
-    hipLaunchKernelGGL(dilate2_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, dy, z, F, H, W, C, OH, OW);
+    EDV_LAUNCH(dilate2_kernel, dim3(ew_blocks(total)), dim3(256), 0, st, dy, z, F, H, W, C, OH, OW);
     EDV_LAUNCH_OK();
     return 0;
 }
@@ -960,7 +960,7 @@ int dilate2(const float *dy, float *z, int F, int H, int W, int C, hipStream_t s
 int pack_conv3x3_bwd(const float *w, float *out, int Cout, int Cin, hipStream_t st) {
     EDV_CHECK(w && out && Cout > 0 && Cin > 0, "shape");
     const int total = Cout * Cin * 9;
-    hipLaunchKernelGGL(pack_conv3x3_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, out, Cout, Cin);
+    EDV_LAUNCH(pack_conv3x3_bwd_kernel, dim3((total + 255) / 256), dim3(256), 0, st, w, out, Cout, Cin);
     EDV_LAUNCH_OK();
     return 0;
 }

@@ -1,6 +1,7 @@
 // Shared device/host helpers for libendodav_hip (gfx950 only; wave = 64 lanes).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
@@ -39,6 +40,27 @@ const char *get_error();
 #define EDV_LAUNCH_OK() EDV_HIP(hipGetLastError())
 
 constexpr int WAVE = 64;
+
+// Kernel timing for edv_profile_enable (round 3).  While the engine has a Bracket open on this thread, every launch carries the bracket's event
+// pair INSIDE its dispatch (hipExtLaunchKernelGGL: the start event is stamped when the kernel starts, the stop event when it ends), so a bracket
+// measures the kernel(s) alone -- the same interval rocprofv3's kernel trace reports -- instead of "the in-order gap before the launch + the kernel"
+// that hipEventRecord before / after the launch measures (12 us against 8 us for a LayerNorm launch in round 2).  A bracket around several launches
+// spans from the first kernel's start to the last one's end.
+struct LaunchTimer {
+    hipEvent_t start = nullptr, stop = nullptr;
+    bool started = false;
+};
+extern thread_local LaunchTimer *g_launch_timer;
+#define EDV_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                                                   \
+    do {                                                                                                                                      \
+        ::edv::LaunchTimer *lt_ = ::edv::g_launch_timer;                                                                                      \
+        if (lt_) {                                                                                                                            \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, stream, lt_->started ? nullptr : lt_->start, lt_->stop, 0, __VA_ARGS__);        \
+            lt_->started = true;                                                                                                              \
+        } else {                                                                                                                              \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                                              \
+        }                                                                                                                                     \
+    } while (0)
 
 // Launch geometry that depends on the DEVICE (resident workgroups of a persistent kernel = CUs x occupancy) is cached per HIP device, not per
 // process: nn.DataParallel drives several devices from one process, and a partitioned or mixed node may give them different CU counts.

@@ -274,8 +274,8 @@ __global__ __launch_bounds__(256, 4) void conv3_dma_kernel(const GemmDesc g, con
 
 template <int WGM, int EP, bool SPLIT>
 void launch_variant(const GemmDesc &d, const GemmSplit &sp, bool buf, unsigned grid, hipStream_t st) {
-    if (buf) hipLaunchKernelGGL((conv3_dma_kernel<WGM, EP, SPLIT, true>), dim3(grid), dim3(256), 0, st, d, sp);
-    else hipLaunchKernelGGL((conv3_dma_kernel<WGM, EP, SPLIT, false>), dim3(grid), dim3(256), 0, st, d, sp);
+    if (buf) EDV_LAUNCH((conv3_dma_kernel<WGM, EP, SPLIT, true>), dim3(grid), dim3(256), 0, st, d, sp);
+    else EDV_LAUNCH((conv3_dma_kernel<WGM, EP, SPLIT, false>), dim3(grid), dim3(256), 0, st, d, sp);
 }
 
 // (Build note, hipcc 7.2: in the HOST pass an amdgcn builtin whose integer arguments need an implicit conversion from a captured lvalue makes

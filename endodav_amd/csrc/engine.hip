@@ -22,6 +22,7 @@
 
 namespace edv {
 static thread_local std::string g_err;
+thread_local LaunchTimer *g_launch_timer = nullptr;
 void set_error(const std::string &m) { g_err = m; }
 const char *get_error() { return g_err.c_str(); }
 }  // namespace edv
@@ -122,10 +123,12 @@ int alloc_buf(edv_ctx *c, std::unordered_map<std::string, Buf> &pool, const std:
     return 0;
 }
 
-// Records a start/stop event pair around one launch when its class is being profiled.  The events sit on
-// the launch stream, so the pair measures that kernel's execution (plus the in-order gap before it).
+// Times the launch(es) made while it is alive when their class is being profiled: the event pair travels inside the dispatches (EDV_LAUNCH,
+// common.hpp), so the pair measures the kernels alone, as rocprofv3's kernel trace does.  Brackets nest like scopes (an inner one times its own launches).
 struct Bracket {
-    hipEvent_t stop = nullptr;
+    LaunchTimer timer;
+    LaunchTimer *prev = nullptr;
+    bool on = false;
     hipStream_t st;
     Bracket(edv_ctx *c, int cls, hipStream_t s) : st(s) {
         if (!(c->prof_mask & (1u << (cls == KC_LINEAR_ENC ? KC_LINEAR : cls)))) return;  // the sub-class shares its parent's mask bit
@@ -136,11 +139,19 @@ struct Bracket {
             p.ev.emplace_back(a, b);
         }
         auto &pr = p.ev[p.used++];
-        (void)hipEventRecord(pr.first, st);
-        stop = pr.second;
+        timer.start = pr.first;
+        timer.stop = pr.second;
+        prev = g_launch_timer;
+        g_launch_timer = &timer;
+        on = true;
     }
     ~Bracket() {
-        if (stop) (void)hipEventRecord(stop, st);
+        if (!on) return;
+        g_launch_timer = prev;
+        if (!timer.started) {  // nothing was launched inside: keep the pair well-formed (zero-length interval on the stream)
+            (void)hipEventRecord(timer.start, st);
+            (void)hipEventRecord(timer.stop, st);
+        }
     }
 };
 

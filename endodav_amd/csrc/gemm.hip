@@ -191,19 +191,19 @@ void launch_rows(const GemmDesc &d, dim3 grid, hipStream_t st) {
     const int ep = FASTEP ? epilogue_kind(d) : 0;
     if constexpr (FASTEP) {
         if (ep == 1) {
-            hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, LOADER, STORE_ROWS, 1>), grid, block, 0, st, d);
+            EDV_LAUNCH((gemm_kernel<BM, BN, WGM, WGN, LOADER, STORE_ROWS, 1>), grid, block, 0, st, d);
             return;
         }
         if (ep == 2) {
-            hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, LOADER, STORE_ROWS, 2>), grid, block, 0, st, d);
+            EDV_LAUNCH((gemm_kernel<BM, BN, WGM, WGN, LOADER, STORE_ROWS, 2>), grid, block, 0, st, d);
             return;
         }
         if (ep == 3) {
-            hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, LOADER, STORE_ROWS, 3>), grid, block, 0, st, d);
+            EDV_LAUNCH((gemm_kernel<BM, BN, WGM, WGN, LOADER, STORE_ROWS, 3>), grid, block, 0, st, d);
             return;
         }
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, LOADER, STORE_ROWS, 0>), grid, block, 0, st, d);
+    EDV_LAUNCH((gemm_kernel<BM, BN, WGM, WGN, LOADER, STORE_ROWS, 0>), grid, block, 0, st, d);
 }
 
 template <int BM, int BN, int WGM, int WGN, bool FASTEP>
@@ -216,7 +216,7 @@ int launch_tile(const GemmDesc &d, hipStream_t st) {
     else if (d.loader == LOAD_CONV3 && d.store == STORE_ROWS)
         launch_rows<BM, BN, WGM, WGN, LOAD_CONV3, FASTEP>(d, grid, st);
     else if (d.loader == LOAD_DENSE && d.store == STORE_SHUFFLE)
-        hipLaunchKernelGGL((gemm_kernel<BM, BN, WGM, WGN, LOAD_DENSE, STORE_SHUFFLE, 0>), grid, block, 0, st, d);
+        EDV_LAUNCH((gemm_kernel<BM, BN, WGM, WGN, LOAD_DENSE, STORE_SHUFFLE, 0>), grid, block, 0, st, d);
     else
         EDV_CHECK(false, "unsupported loader/store combination");
     EDV_LAUNCH_OK();

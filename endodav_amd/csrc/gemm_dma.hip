@@ -396,15 +396,15 @@ int launch_dma(const GemmDesc &d, long long tiles, hipStream_t st) {
         sp.ws = d.ws + MAX_COUNTERS;
         EDV_CHECK((size_t)MAX_COUNTERS + (size_t)sp.nsplit * 2 * SLOT <= d.ws_floats && (uintptr_t)d.ws % 16 == 0,
                   "stream-K workspace too small (gemm_workspace)");
-        if (buf && d.a_map.period == 0) hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP, true, 2>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
-        else if (buf) hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP, true, 1>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
-        else hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP, true, 0>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
+        if (buf && d.a_map.period == 0) EDV_LAUNCH((gemm_dma_kernel<STORE, EP, true, 2>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
+        else if (buf) EDV_LAUNCH((gemm_dma_kernel<STORE, EP, true, 1>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
+        else EDV_LAUNCH((gemm_dma_kernel<STORE, EP, true, 0>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
         EDV_LAUNCH_OK();
         return 0;
     }
-    if (buf && d.a_map.period == 0) hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP, false, 2>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
-    else if (buf) hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP, false, 1>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
-    else hipLaunchKernelGGL((gemm_dma_kernel<STORE, EP, false, 0>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
+    if (buf && d.a_map.period == 0) EDV_LAUNCH((gemm_dma_kernel<STORE, EP, false, 2>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
+    else if (buf) EDV_LAUNCH((gemm_dma_kernel<STORE, EP, false, 1>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
+    else EDV_LAUNCH((gemm_dma_kernel<STORE, EP, false, 0>), dim3((unsigned)grid), dim3(256), 0, st, d, sp);
     EDV_LAUNCH_OK();
     return 0;
 }
@@ -412,8 +412,8 @@ int launch_dma(const GemmDesc &d, long long tiles, hipStream_t st) {
 // GEGLU epilogue (EP = 6): shallow tiles (K = C of a motion module), always the plain grid, buffer descriptors only (gemm_geglu_supported)
 int launch_geglu(const GemmDesc &d, long long tiles, hipStream_t st) {
     const GemmSplit sp{1, 1, 0, 1, 0, nullptr, nullptr};
-    if (d.a_map.period == 0) hipLaunchKernelGGL((gemm_dma_kernel<STORE_ROWS, 6, false, 2>), dim3((unsigned)tiles), dim3(256), 0, st, d, sp);
-    else hipLaunchKernelGGL((gemm_dma_kernel<STORE_ROWS, 6, false, 1>), dim3((unsigned)tiles), dim3(256), 0, st, d, sp);
+    if (d.a_map.period == 0) EDV_LAUNCH((gemm_dma_kernel<STORE_ROWS, 6, false, 2>), dim3((unsigned)tiles), dim3(256), 0, st, d, sp);
+    else EDV_LAUNCH((gemm_dma_kernel<STORE_ROWS, 6, false, 1>), dim3((unsigned)tiles), dim3(256), 0, st, d, sp);
     EDV_LAUNCH_OK();
     return 0;
 }

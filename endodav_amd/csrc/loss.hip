@@ -278,9 +278,9 @@ int photometric_loss(const float *frames, const float *const disp[4], const int 
     const float inv_nx = (float)(1.0 / ((double)N * H * (W - 1))), inv_ny = (float)(1.0 / ((double)N * (H - 1) * W));
 
     EDV_HIP(hipMemsetAsync(loss, 0, sizeof(float), st));
-    hipLaunchKernelGGL(cam_kernel, dim3((2 * N + 63) / 64), dim3(64), 0, st, K, invK, Tprev, Tnext, cams, N);
+    EDV_LAUNCH(cam_kernel, dim3((2 * N + 63) / 64), dim3(64), 0, st, K, invK, Tprev, Tnext, cams, N);
     EDV_LAUNCH_OK();
-    hipLaunchKernelGGL(kept_kernel, dim3((kept_n + 63) / 64), dim3(64), 0, st, kept, B, T);
+    EDV_LAUNCH(kept_kernel, dim3((kept_n + 63) / 64), dim3(64), 0, st, kept, B, T);
     EDV_LAUNCH_OK();
     for (int s = 0; s < 4; ++s) {
         EDV_CHECK(disp[s] && grad[s] && dh[s] > 0 && dw[s] > 0, "bad disparity map");
@@ -292,21 +292,21 @@ int photometric_loss(const float *frames, const float *const disp[4], const int 
         }
         // weights of this scale's terms in the total (trainer :948-966: / 2 per neighbour pair, smoothness / 2^s, mean over the 4 scales)
         const float w_rep = 0.25f * 0.5f / cnt, w_sm = 0.25f * smoothness / (float)(1 << s);
-        hipLaunchKernelGGL(frame_sum_kernel, dim3(SUM_PARTS, N), dim3(256), 0, st, D, sum_part, P);
+        EDV_LAUNCH(frame_sum_kernel, dim3(SUM_PARTS, N), dim3(256), 0, st, D, sum_part, P);
         EDV_LAUNCH_OK();
-        hipLaunchKernelGGL(frame_sum_finish_kernel, dim3(N), dim3(64), 0, st, sum_part, mean, (float)(1.0 / (double)P));
+        EDV_LAUNCH(frame_sum_finish_kernel, dim3(N), dim3(64), 0, st, sum_part, mean, (float)(1.0 / (double)P));
         EDV_LAUNCH_OK();
-        hipLaunchKernelGGL(smooth_kernel, dim3(sm_blocks, N), dim3(256), 0, st, D, frames, mean, gsm, sm_part, H, W, inv_nx, inv_ny);
+        EDV_LAUNCH(smooth_kernel, dim3(sm_blocks, N), dim3(256), 0, st, D, frames, mean, gsm, sm_part, H, W, inv_nx, inv_ny);
         EDV_LAUNCH_OK();
-        hipLaunchKernelGGL(warp_kernel, dim3(pix_blocks, N, 2), dim3(256), 0, st, D, frames, cams, xw, N, T, H, W, da, db);
+        EDV_LAUNCH(warp_kernel, dim3(pix_blocks, N, 2), dim3(256), 0, st, D, frames, cams, xw, N, T, H, W, da, db);
         EDV_LAUNCH_OK();
-        hipLaunchKernelGGL(ssim_kernel, dim3(tiles, 3, 2 * kept_n), dim3(256), 0, st, xw, frames, gx, ssim_part, kept, N, H, W, tiles_x, w_rep * 0.85f / 3.0f,
+        EDV_LAUNCH(ssim_kernel, dim3(tiles, 3, 2 * kept_n), dim3(256), 0, st, xw, frames, gx, ssim_part, kept, N, H, W, tiles_x, w_rep * 0.85f / 3.0f,
                            w_rep * 0.15f / 3.0f);
         EDV_LAUNCH_OK();
-        hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(256), 0, st, ssim_part, (long long)2 * kept_n * 3 * tiles, sm_part, sm_blocks, N, S, loss, w_sm, inv_nx, inv_ny);
+        EDV_LAUNCH(finish_kernel, dim3(1), dim3(256), 0, st, ssim_part, (long long)2 * kept_n * 3 * tiles, sm_part, sm_blocks, N, S, loss, w_sm, inv_nx, inv_ny);
         EDV_LAUNCH_OK();
         float *gdst = same ? grad[s] : gD;
-        hipLaunchKernelGGL(warp_bwd_kernel, dim3(pix_blocks, N), dim3(256), 0, st, D, frames, cams, gx, gsm, mean, S, gdst, N, T, H, W, da, db, w_sm);
+        EDV_LAUNCH(warp_bwd_kernel, dim3(pix_blocks, N), dim3(256), 0, st, D, frames, cams, gx, gsm, mean, S, gdst, N, T, H, W, da, db, w_sm);
         EDV_LAUNCH_OK();
         if (!same) EDV_TRY(bilinear_bwd(gD, grad[s], N, dh[s], dw[s], 1, H, W, false, st));
     }

@@ -690,12 +690,12 @@ int trainer_loss(const TrainerLossIn &in, int N, int H, int W, const TrainerLoss
     if (g.invK) EDV_HIP(hipMemsetAsync(g.invK, 0, (size_t)N * 16 * sizeof(float), st));
     for (int nb = 0; nb < 2; ++nb)
         if (g.T[nb]) EDV_HIP(hipMemsetAsync(g.T[nb], 0, (size_t)N * 16 * sizeof(float), st));
-    hipLaunchKernelGGL(cam_kernel, dim3((2 * N + 63) / 64), dim3(64), 0, st, in.K, in.invK, in.T[0], in.T[1], cams, N);
+    EDV_LAUNCH(cam_kernel, dim3((2 * N + 63) / 64), dim3(64), 0, st, in.K, in.invK, in.T[0], in.T[1], cams, N);
     EDV_LAUNCH_OK();
     for (int nb = 0; nb < 2; ++nb) {
-        hipLaunchKernelGGL(mask_sums_kernel, dim3(N), dim3(256), 0, st, in.mask[nb], mpart, H, W);
+        EDV_LAUNCH(mask_sums_kernel, dim3(N), dim3(256), 0, st, in.mask[nb], mpart, H, W);
         EDV_LAUNCH_OK();
-        hipLaunchKernelGGL(mask_sums_finish_kernel, dim3(1), dim3(64), 0, st, mpart, msum + nb * 4, N);
+        EDV_LAUNCH(mask_sums_finish_kernel, dim3(1), dim3(64), 0, st, mpart, msum + nb * 4, N);
         EDV_LAUNCH_OK();
     }
     for (int s = 0; s < 4; ++s) {
@@ -719,83 +719,83 @@ int trainer_loss(const TrainerLossIn &in, int N, int H, int W, const TrainerLoss
         // ---- smoothness at the colour scale ----
         const float w_sm = wt.disparity_smoothness / (float)(1 << s);
         const float inv_nx = (float)(1.0 / ((double)N * Hc * (Wc - 1))), inv_ny = (float)(1.0 / ((double)N * (Hc - 1) * Wc));
-        hipLaunchKernelGGL(frame_sum_kernel, dim3(SUM_PARTS, N), dim3(256), 0, st, Dc, sum_part, Pc);
+        EDV_LAUNCH(frame_sum_kernel, dim3(SUM_PARTS, N), dim3(256), 0, st, Dc, sum_part, Pc);
         EDV_LAUNCH_OK();
-        hipLaunchKernelGGL(frame_sum_finish_kernel, dim3(N), dim3(64), 0, st, sum_part, mean, (float)(1.0 / (double)Pc));
+        EDV_LAUNCH(frame_sum_finish_kernel, dim3(N), dim3(64), 0, st, sum_part, mean, (float)(1.0 / (double)Pc));
         EDV_LAUNCH_OK();
-        hipLaunchKernelGGL(smooth_kernel, dim3(SM_BLOCKS, N), dim3(256), 0, st, Dc, in.color[s], mean, gsm, sm_part, Hc, Wc, inv_nx, inv_ny);
+        EDV_LAUNCH(smooth_kernel, dim3(SM_BLOCKS, N), dim3(256), 0, st, Dc, in.color[s], mean, gsm, sm_part, Hc, Wc, inv_nx, inv_ny);
         EDV_LAUNCH_OK();
         // ---- the two neighbours: warp, weighted SSIM / L1 / transform term, appearance-flow smoothness ----
         for (int nb = 0; nb < 2; ++nb) {
             float *xw_nb = xw + (size_t)nb * N * 3 * P, *gx_nb = gx + (size_t)nb * N * 3 * P;
-            hipLaunchKernelGGL(warp_nb_kernel, dim3(pix_blocks, N), dim3(256), 0, st, D, in.color_nb[nb], cams, nb, xw_nb, H, W, da, db);
+            EDV_LAUNCH(warp_nb_kernel, dim3(pix_blocks, N), dim3(256), 0, st, D, in.color_nb[nb], cams, nb, xw_nb, H, W, da, db);
             EDV_LAUNCH_OK();
             // per-scale weights: rep / 2, tc tr / 2 (trainer :953-954); the 1/4 of the mean over scales multiplies every GRADIENT below (0.25 * ...)
-            hipLaunchKernelGGL(ssimw_kernel, dim3(tiles, 3, N), dim3(256), 0, st, xw_nb, in.refined[s][nb], in.registration[0][nb], in.mask[nb], msum + nb * 4, gx_nb,
+            EDV_LAUNCH(ssimw_kernel, dim3(tiles, 3, N), dim3(256), 0, st, xw_nb, in.refined[s][nb], in.registration[0][nb], in.mask[nb], msum + nb * 4, gx_nb,
                                g.refined[s][nb], ws + L.ssim_part[nb], H, W, tiles_x, 0.5f, 0.5f * wt.transform_constraint);
             EDV_LAUNCH_OK();
-            hipLaunchKernelGGL(cvt_kernel, dim3(CVT_BLOCKS, N), dim3(256), 0, st, in.transform[s][nb], in.color[0], in.registration[s][nb], in.mask[nb], msum + nb * 4,
+            EDV_LAUNCH(cvt_kernel, dim3(CVT_BLOCKS, N), dim3(256), 0, st, in.transform[s][nb], in.color[0], in.registration[s][nb], in.mask[nb], msum + nb * 4,
                                g.transform[s][nb], ws + L.cvt_part[nb], H, W, 0.5f * wt.transform_smoothness);
             EDV_LAUNCH_OK();
         }
         // ---- depth-consistency sums (their means need the counts before the gradients) ----
         const float w_dr = tw * wt.depth_reproj * 0.5f, w_df = tw * wt.depth_flow * 0.5f;
         if (do_dr) {
-            hipLaunchKernelGGL(dreproj_fwd_kernel, dim3(PAIR_BLOCKS, N, 2), dim3(256), 0, st, D, cams, pair_part, N, H, W, da, db);
+            EDV_LAUNCH(dreproj_fwd_kernel, dim3(PAIR_BLOCKS, N, 2), dim3(256), 0, st, D, cams, pair_part, N, H, W, da, db);
             EDV_LAUNCH_OK();
-            hipLaunchKernelGGL(pair_sums_kernel, dim3(1), dim3(256), 0, st, pair_part, (long long)N * PAIR_BLOCKS, drp_tot);
+            EDV_LAUNCH(pair_sums_kernel, dim3(1), dim3(256), 0, st, pair_part, (long long)N * PAIR_BLOCKS, drp_tot);
             EDV_LAUNCH_OK();
         }
         if (do_df) {
             for (int nb = 0; nb < 2; ++nb) {
-                hipLaunchKernelGGL(dflow_fwd_kernel, dim3(PAIR_BLOCKS, N), dim3(256), 0, st, D, in.position[s][nb], nb, pair_part, N, H, W, da, db);
+                EDV_LAUNCH(dflow_fwd_kernel, dim3(PAIR_BLOCKS, N), dim3(256), 0, st, D, in.position[s][nb], nb, pair_part, N, H, W, da, db);
                 EDV_LAUNCH_OK();
             }
-            hipLaunchKernelGGL(pair_sums_kernel, dim3(1), dim3(256), 0, st, pair_part, (long long)N * PAIR_BLOCKS, dfl_tot);
+            EDV_LAUNCH(pair_sums_kernel, dim3(1), dim3(256), 0, st, pair_part, (long long)N * PAIR_BLOCKS, dfl_tot);
             EDV_LAUNCH_OK();
         }
         FinishArgs fa{{ws + L.ssim_part[0], ws + L.ssim_part[1]}, (long long)N * 3 * tiles, {ws + L.cvt_part[0], ws + L.cvt_part[1]}, N * CVT_BLOCKS, sm_part, SM_BLOCKS, N,
                       do_dr ? drp_tot : nullptr, do_df ? dfl_tot : nullptr, w_sm, inv_nx, inv_ny, w_dr, w_df};
-        hipLaunchKernelGGL(finish_scale_kernel, dim3(1), dim3(256), 0, st, fa, S, losses, s);
+        EDV_LAUNCH(finish_scale_kernel, dim3(1), dim3(256), 0, st, fa, S, losses, s);
         EDV_LAUNCH_OK();
         // ---- gradients.  The kernels above produced d(loss_s)/d(.) for refined, transform_high and the warped images; total = mean over scales -> x 0.25 ----
         if (do_dr || do_df) EDV_HIP(hipMemsetAsync(gdep, 0, (size_t)N * P * sizeof(float), st));
         const int gb = pose ? POSE_BLOCKS : pix_blocks;
         if (pose && do_dr)
-            hipLaunchKernelGGL((geom_bwd_kernel<true, true>), dim3(gb, N), dim3(256), 0, st, D, in.color_nb[0], in.color_nb[1], cams, gx, drp_tot, gdg, gdep, pose_part, N, H, W, da, db, w_dr);
+            EDV_LAUNCH((geom_bwd_kernel<true, true>), dim3(gb, N), dim3(256), 0, st, D, in.color_nb[0], in.color_nb[1], cams, gx, drp_tot, gdg, gdep, pose_part, N, H, W, da, db, w_dr);
         else if (pose)
-            hipLaunchKernelGGL((geom_bwd_kernel<true, false>), dim3(gb, N), dim3(256), 0, st, D, in.color_nb[0], in.color_nb[1], cams, gx, drp_tot, gdg, gdep, pose_part, N, H, W, da, db, w_dr);
+            EDV_LAUNCH((geom_bwd_kernel<true, false>), dim3(gb, N), dim3(256), 0, st, D, in.color_nb[0], in.color_nb[1], cams, gx, drp_tot, gdg, gdep, pose_part, N, H, W, da, db, w_dr);
         else if (do_dr)
-            hipLaunchKernelGGL((geom_bwd_kernel<false, true>), dim3(gb, N), dim3(256), 0, st, D, in.color_nb[0], in.color_nb[1], cams, gx, drp_tot, gdg, gdep, pose_part, N, H, W, da, db, w_dr);
+            EDV_LAUNCH((geom_bwd_kernel<false, true>), dim3(gb, N), dim3(256), 0, st, D, in.color_nb[0], in.color_nb[1], cams, gx, drp_tot, gdg, gdep, pose_part, N, H, W, da, db, w_dr);
         else
-            hipLaunchKernelGGL((geom_bwd_kernel<false, false>), dim3(gb, N), dim3(256), 0, st, D, in.color_nb[0], in.color_nb[1], cams, gx, drp_tot, gdg, gdep, pose_part, N, H, W, da, db, w_dr);
+            EDV_LAUNCH((geom_bwd_kernel<false, false>), dim3(gb, N), dim3(256), 0, st, D, in.color_nb[0], in.color_nb[1], cams, gx, drp_tot, gdg, gdep, pose_part, N, H, W, da, db, w_dr);
         EDV_LAUNCH_OK();
         if (do_df)
             for (int nb = 0; nb < 2; ++nb) {
-                hipLaunchKernelGGL(dflow_bwd_kernel, dim3(pix_blocks, N), dim3(256), 0, st, D, in.position[s][nb], nb, dfl_tot, gdep, N, H, W, da, db, w_df);
+                EDV_LAUNCH(dflow_bwd_kernel, dim3(pix_blocks, N), dim3(256), 0, st, D, in.position[s][nb], nb, dfl_tot, gdep, N, H, W, da, db, w_df);
                 EDV_LAUNCH_OK();
             }
         float *gdst = same ? g.disp[s] : gD;
-        hipLaunchKernelGGL(depth_grad_kernel, dim3(pix_blocks), dim3(256), 0, st, D, gdg, (do_dr || do_df) ? gdep : nullptr, gdst, (long long)N * P, da, db);
+        EDV_LAUNCH(depth_grad_kernel, dim3(pix_blocks), dim3(256), 0, st, D, gdg, (do_dr || do_df) ? gdep : nullptr, gdst, (long long)N * P, da, db);
         EDV_LAUNCH_OK();
         if (!same) EDV_TRY(bilinear_bwd(gD, g.disp[s], N, in.disp_h[s], in.disp_w[s], 1, H, W, false, st));
-        hipLaunchKernelGGL(smooth_grad_kernel, dim3(SM_BLOCKS, N), dim3(256), 0, st, gsm, mean, S, gDc, Pc, w_sm);
+        EDV_LAUNCH(smooth_grad_kernel, dim3(SM_BLOCKS, N), dim3(256), 0, st, gsm, mean, S, gDc, Pc, w_sm);
         EDV_LAUNCH_OK();
         if (same_c) {
-            hipLaunchKernelGGL(add_kernel, dim3(pix_blocks), dim3(256), 0, st, gDc, g.disp[s], (long long)N * Pc);
+            EDV_LAUNCH(add_kernel, dim3(pix_blocks), dim3(256), 0, st, gDc, g.disp[s], (long long)N * Pc);
             EDV_LAUNCH_OK();
         } else {
             EDV_TRY(bilinear_bwd(gDc, g.disp[s], N, in.disp_h[s], in.disp_w[s], 1, Hc, Wc, true, st));
         }
         if (pose) {
-            hipLaunchKernelGGL(pose_finish_kernel, dim3((N + 63) / 64), dim3(64), 0, st, pose_part, gb, in.K, in.T[0], in.T[1], g.K, g.invK, g.T[0], g.T[1], N);
+            EDV_LAUNCH(pose_finish_kernel, dim3((N + 63) / 64), dim3(64), 0, st, pose_part, gb, in.K, in.T[0], in.T[1], g.K, g.invK, g.T[0], g.T[1], N);
             EDV_LAUNCH_OK();
         }
     }
     // the mean over the four scales (trainer :968): every gradient written above is d(loss_s); scale them by 1/4
     auto scale = [&](float *p, long long n) -> int {
         if (!p) return 0;
-        hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0, st, p, n, 0.25f);
+        EDV_LAUNCH(scale_kernel, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0, st, p, n, 0.25f);
         EDV_LAUNCH_OK();
         return 0;
     };

@@ -236,7 +236,7 @@ int layernorm(const float *x, RowMap in_map, const float *w, const float *b, flo
     EDV_CHECK(blocks < (1ll << 31), "grid");
     const int rpf = rows_per_frame > 0 ? rows_per_frame : 1, TT = T > 0 ? T : 1, acc = accumulate ? 1 : 0;
 #define EDV_LN_LAUNCH(RR, NVV)                                                                                                                  \
-    hipLaunchKernelGGL((layernorm_kernel<RR, NVV>), dim3((unsigned)blocks), dim3(256), 0, st, x, in_map, w, b, y, out_map, rows, dim, eps, pe, rpf, TT, \
+    EDV_LAUNCH((layernorm_kernel<RR, NVV>), dim3((unsigned)blocks), dim3(256), 0, st, x, in_map, w, b, y, out_map, rows, dim, eps, pe, rpf, TT, \
                        act, acc)
     if (dim <= 512) {
         if (R == 4) EDV_LN_LAUNCH(4, 2);
@@ -261,17 +261,17 @@ int groupnorm(const float *x, const float *w, const float *b, float *y, float *s
     const int nch = (P + GN_ROWS - 1) / GN_ROWS;
     if (part && C <= 1024 && nch <= 65535) {  // coalesced two-stage statistics
         EDV_CHECK(groupnorm_workspace(F, P, C) <= part_floats && (uintptr_t)part % 16 == 0, "groupnorm workspace too small (groupnorm_workspace)");
-        hipLaunchKernelGGL(groupnorm_partial_kernel, dim3(nch, F), dim3(256), 0, st, x, part, P, C, nch);
+        EDV_LAUNCH(groupnorm_partial_kernel, dim3(nch, F), dim3(256), 0, st, x, part, P, C, nch);
         EDV_LAUNCH_OK();
-        hipLaunchKernelGGL(groupnorm_finish_kernel, dim3(groups, F), dim3(64), 0, st, part, stats, P, C, groups, nch, eps);
+        EDV_LAUNCH(groupnorm_finish_kernel, dim3(groups, F), dim3(64), 0, st, part, stats, P, C, groups, nch, eps);
         EDV_LAUNCH_OK();
     } else {
-        hipLaunchKernelGGL(groupnorm_stats_kernel, dim3(groups, F), dim3(256), 0, st, x, stats, P, C, groups, eps);
+        EDV_LAUNCH(groupnorm_stats_kernel, dim3(groups, F), dim3(256), 0, st, x, stats, P, C, groups, eps);
         EDV_LAUNCH_OK();
     }
     const long long total4 = (long long)F * P * C / 4;
     const int blocks = (int)((total4 + 255) / 256 < 4096 ? (total4 + 255) / 256 : 4096);
-    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(blocks), dim3(256), 0, st, x, stats, w, b, y, total4, P, C, groups);
+    EDV_LAUNCH(groupnorm_apply_kernel, dim3(blocks), dim3(256), 0, st, x, stats, w, b, y, total4, P, C, groups);
     EDV_LAUNCH_OK();
     return 0;
 }

@@ -104,21 +104,21 @@ __global__ void pack_geglu_kernel(const float *__restrict__ w, const float *__re
 
 int pack_geglu(const float *w, const float *b, float *wi, float *bi, int N, int K, hipStream_t st) {
     EDV_CHECK(w && b && wi && bi && N > 0 && K > 0 && N % 64 == 0, "pack_geglu: N (both halves) must be a multiple of 64");
-    hipLaunchKernelGGL(pack_geglu_kernel, dim3(blocks_for((long long)N * K)), dim3(256), 0, st, w, b, wi, bi, N, K);
+    EDV_LAUNCH(pack_geglu_kernel, dim3(blocks_for((long long)N * K)), dim3(256), 0, st, w, b, wi, bi, N, K);
     EDV_LAUNCH_OK();
     return 0;
 }
 
 int pack_conv3x3(const float *w, float *out, int Cout, int Cin, hipStream_t st) {
     EDV_CHECK(w && out && Cout > 0 && Cin > 0, "bad operand");
-    hipLaunchKernelGGL(pack_conv3x3_kernel, dim3(blocks_for((long long)Cout * Cin * 9)), dim3(256), 0, st, w, out, Cout, Cin);
+    EDV_LAUNCH(pack_conv3x3_kernel, dim3(blocks_for((long long)Cout * Cin * 9)), dim3(256), 0, st, w, out, Cout, Cin);
     EDV_LAUNCH_OK();
     return 0;
 }
 
 int pack_convT(const float *w, float *wout, const float *b, float *bout, int Cin, int Cout, int s, hipStream_t st) {
     EDV_CHECK(w && wout && b && bout && Cin > 0 && Cout > 0 && s > 0, "bad operand");
-    hipLaunchKernelGGL(pack_convT_kernel, dim3(blocks_for((long long)s * s * Cout * Cin)), dim3(256), 0, st, w, wout, b, bout, Cin, Cout, s);
+    EDV_LAUNCH(pack_convT_kernel, dim3(blocks_for((long long)s * s * Cout * Cin)), dim3(256), 0, st, w, wout, b, bout, Cin, Cout, s);
     EDV_LAUNCH_OK();
     return 0;
 }
@@ -126,7 +126,7 @@ int pack_convT(const float *w, float *wout, const float *b, float *bout, int Cin
 int copy_f32(const float *src, float *dst, long long n, hipStream_t st) {
     EDV_CHECK(src && dst && n > 0, "bad operand");
     const long long b = (n + 255) / 256;
-    hipLaunchKernelGGL(copy_kernel, dim3((unsigned)(b < 8192 ? b : 8192)), dim3(256), 0, st, src, dst, n);
+    EDV_LAUNCH(copy_kernel, dim3((unsigned)(b < 8192 ? b : 8192)), dim3(256), 0, st, src, dst, n);
     EDV_LAUNCH_OK();
     return 0;
 }
@@ -134,21 +134,21 @@ int copy_f32(const float *src, float *dst, long long n, hipStream_t st) {
 int fold_lora(const float *W, const float *A, const float *B, const float *U, const float *V, float scale, float *out, int nout, int nin, int r,
               hipStream_t st) {
     EDV_CHECK(W && A && B && out && nout > 0 && nin > 0 && r > 0, "bad operand");
-    hipLaunchKernelGGL(fold_lora_kernel, dim3(blocks_for((long long)nout * nin)), dim3(256), 0, st, W, A, B, U, V, scale, out, nout, nin, r);
+    EDV_LAUNCH(fold_lora_kernel, dim3(blocks_for((long long)nout * nin)), dim3(256), 0, st, W, A, B, U, V, scale, out, nout, nin, r);
     EDV_LAUNCH_OK();
     return 0;
 }
 
 int fold_ssb(const float *W, const float *a, const float *b, float *out, int nout, int nin, hipStream_t st) {
     EDV_CHECK(W && a && b && out && nout > 0 && nin > 0, "bad operand");
-    hipLaunchKernelGGL(fold_ssb_kernel, dim3(blocks_for((long long)nout * nin)), dim3(256), 0, st, W, a, b, out, nout, nin);
+    EDV_LAUNCH(fold_ssb_kernel, dim3(blocks_for((long long)nout * nin)), dim3(256), 0, st, W, a, b, out, nout, nin);
     EDV_LAUNCH_OK();
     return 0;
 }
 
 int fold_dash(const float *Utop, const float *idx, const float *Vtop, float *inout, int nout, int nin, int r, hipStream_t st) {
     EDV_CHECK(Utop && idx && Vtop && inout && nout > 0 && nin > 0 && r > 0, "bad operand");
-    hipLaunchKernelGGL(fold_dash_kernel, dim3(blocks_for((long long)nout * nin)), dim3(256), 0, st, Utop, idx, Vtop, inout, nout, nin, r);
+    EDV_LAUNCH(fold_dash_kernel, dim3(blocks_for((long long)nout * nin)), dim3(256), 0, st, Utop, idx, Vtop, inout, nout, nin, r);
     EDV_LAUNCH_OK();
     return 0;
 }
@@ -156,7 +156,7 @@ int fold_dash(const float *Utop, const float *idx, const float *Vtop, float *ino
 int fold_bn(float *w, const float *b, const float *gamma, const float *beta, const float *mean, const float *var, float eps, float *bout, int nout, int K,
             hipStream_t st) {
     EDV_CHECK(w && b && gamma && beta && mean && var && bout && nout > 0 && K > 0, "bad operand");
-    hipLaunchKernelGGL(fold_bn_kernel, dim3(blocks_for((long long)nout * K)), dim3(256), 0, st, w, b, gamma, beta, mean, var, eps, bout, nout, K);
+    EDV_LAUNCH(fold_bn_kernel, dim3(blocks_for((long long)nout * K)), dim3(256), 0, st, w, b, gamma, beta, mean, var, eps, bout, nout, K);
     EDV_LAUNCH_OK();
     return 0;
 }

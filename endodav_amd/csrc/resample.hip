@@ -208,7 +208,7 @@ int patchify(const float *x, float *cols, int F, int H, int W, int ih, int iw, h
     EDV_CHECK(F > 0 && H > 0 && W > 0 && ld >= 588, "empty problem");
     EDV_CHECK(ih % 14 == 0 && iw % 14 == 0 && ih > 0 && iw > 0, "image_shape must be a multiple of 14");
     const long long total = (long long)F * (ih / 14) * (iw / 14) * ld;
-    hipLaunchKernelGGL(patchify_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, st, x, cols, F, H, W, ih, iw, lin_ratio(H, ih), lin_ratio(W, iw), ld);
+    EDV_LAUNCH(patchify_kernel, dim3(grid_for(total, 16384)), dim3(256), 0, st, x, cols, F, H, W, ih, iw, lin_ratio(H, ih), lin_ratio(W, iw), ld);
     EDV_LAUNCH_OK();
     return 0;
 }
@@ -221,9 +221,9 @@ int bilinear(const float *x, float *y, int F, int H, int W, int C, int OH, int O
     EDV_CHECK(!add || C % 4 == 0, "bilinear: the addend needs C % 4 == 0");
     const float rh = lin_ratio(H, OH), rw = lin_ratio(W, OW);
     if (C == 1) {
-        hipLaunchKernelGGL(bilinear_c1_kernel, dim3(grid_for((long long)F * OH * OW)), dim3(256), 0, st, x, y, F, H, W, OH, OW, rh, rw);
+        EDV_LAUNCH(bilinear_c1_kernel, dim3(grid_for((long long)F * OH * OW)), dim3(256), 0, st, x, y, F, H, W, OH, OW, rh, rw);
     } else {
-        hipLaunchKernelGGL(bilinear_c4_kernel, dim3(grid_for((long long)F * OH * OW * (C / 4), 16384)), dim3(256), 0, st, x, y, F, H, W, C / 4, OH, OW,
+        EDV_LAUNCH(bilinear_c4_kernel, dim3(grid_for((long long)F * OH * OW * (C / 4), 16384)), dim3(256), 0, st, x, y, F, H, W, C / 4, OH, OW,
                            rh, rw, add);
     }
     EDV_LAUNCH_OK();
@@ -239,13 +239,13 @@ int dot_channels(const float *x, const float *w, const float *b, float *y, long 
     EDV_CHECK(blocks < (1ll << 31), "grid");
     dim3 grid((unsigned)blocks), block(256);
     switch (lpp) {
-        case 1: hipLaunchKernelGGL(dot_channels_kernel<1>, grid, block, 0, st, x, w, b, y, M, act); break;
-        case 2: hipLaunchKernelGGL(dot_channels_kernel<2>, grid, block, 0, st, x, w, b, y, M, act); break;
-        case 4: hipLaunchKernelGGL(dot_channels_kernel<4>, grid, block, 0, st, x, w, b, y, M, act); break;
-        case 8: hipLaunchKernelGGL(dot_channels_kernel<8>, grid, block, 0, st, x, w, b, y, M, act); break;
-        case 16: hipLaunchKernelGGL(dot_channels_kernel<16>, grid, block, 0, st, x, w, b, y, M, act); break;
-        case 32: hipLaunchKernelGGL(dot_channels_kernel<32>, grid, block, 0, st, x, w, b, y, M, act); break;
-        default: hipLaunchKernelGGL(dot_channels_kernel<64>, grid, block, 0, st, x, w, b, y, M, act); break;
+        case 1: EDV_LAUNCH(dot_channels_kernel<1>, grid, block, 0, st, x, w, b, y, M, act); break;
+        case 2: EDV_LAUNCH(dot_channels_kernel<2>, grid, block, 0, st, x, w, b, y, M, act); break;
+        case 4: EDV_LAUNCH(dot_channels_kernel<4>, grid, block, 0, st, x, w, b, y, M, act); break;
+        case 8: EDV_LAUNCH(dot_channels_kernel<8>, grid, block, 0, st, x, w, b, y, M, act); break;
+        case 16: EDV_LAUNCH(dot_channels_kernel<16>, grid, block, 0, st, x, w, b, y, M, act); break;
+        case 32: EDV_LAUNCH(dot_channels_kernel<32>, grid, block, 0, st, x, w, b, y, M, act); break;
+        default: EDV_LAUNCH(dot_channels_kernel<64>, grid, block, 0, st, x, w, b, y, M, act); break;
     }
     EDV_LAUNCH_OK();
     return 0;
@@ -253,21 +253,21 @@ int dot_channels(const float *x, const float *w, const float *b, float *y, long 
 
 int cls_rows(const float *cls, const float *pos, float *tokens, int F, int ntok, int D, hipStream_t st) {
     EDV_CHECK(cls && pos && tokens, "null operand");
-    hipLaunchKernelGGL(cls_rows_kernel, dim3(grid_for((long long)F * D, 1 << 30)), dim3(256), 0, st, cls, pos, tokens, F, ntok, D);
+    EDV_LAUNCH(cls_rows_kernel, dim3(grid_for((long long)F * D, 1 << 30)), dim3(256), 0, st, cls, pos, tokens, F, ntok, D);
     EDV_LAUNCH_OK();
     return 0;
 }
 
 int sigmoid_inplace(float *x, long long n, hipStream_t st) {
     EDV_CHECK(x && n > 0, "bad operand");
-    hipLaunchKernelGGL(sigmoid_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, n);
+    EDV_LAUNCH(sigmoid_kernel, dim3(grid_for(n)), dim3(256), 0, st, x, n);
     EDV_LAUNCH_OK();
     return 0;
 }
 
 int resize_bicubic(const float *x, float *y, int NP, int H, int W, int OH, int OW, hipStream_t st) {
     EDV_CHECK(x && y && NP > 0 && H > 0 && W > 0 && OH > 0 && OW > 0, "bad operand");
-    hipLaunchKernelGGL(resize_bicubic_kernel, dim3(grid_for((long long)NP * OH * OW, 16384)), dim3(256), 0, st, x, y, NP, H, W, OH, OW,
+    EDV_LAUNCH(resize_bicubic_kernel, dim3(grid_for((long long)NP * OH * OW, 16384)), dim3(256), 0, st, x, y, NP, H, W, OH, OW,
                        (float)H / (float)OH, (float)W / (float)OW);
     EDV_LAUNCH_OK();
     return 0;
@@ -275,7 +275,7 @@ int resize_bicubic(const float *x, float *y, int NP, int H, int W, int OH, int O
 
 int bicubic_pos(const float *grid, float *out, int S, int D, int oh, int ow, float scale_h, float scale_w, hipStream_t st) {
     EDV_CHECK(grid && out && S > 0 && D > 0 && oh > 0 && ow > 0, "bad operand");
-    hipLaunchKernelGGL(bicubic_pos_kernel, dim3(grid_for((long long)oh * ow * D, 1 << 30)), dim3(256), 0, st, grid, out, S, D, oh, ow, scale_h, scale_w);
+    EDV_LAUNCH(bicubic_pos_kernel, dim3(grid_for((long long)oh * ow * D, 1 << 30)), dim3(256), 0, st, grid, out, S, D, oh, ow, scale_h, scale_w);
     EDV_LAUNCH_OK();
     return 0;
 }

@@ -264,36 +264,36 @@ int attn_temporal(const float *qkv, float *out, int B, int T, int P, int C, int 
         const dim3 b3((unsigned)(((T * HG + 63) / 64) * 64));
         const size_t lds = (size_t)T * 3 * HG * d * sizeof(float);
         if (T <= 8)
-            hipLaunchKernelGGL(attn_temporal_pixel_kernel<8>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
+            EDV_LAUNCH(attn_temporal_pixel_kernel<8>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
         else if (T <= 16)
-            hipLaunchKernelGGL(attn_temporal_pixel_kernel<16>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
+            EDV_LAUNCH(attn_temporal_pixel_kernel<16>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
         else if (T <= 32)
-            hipLaunchKernelGGL(attn_temporal_pixel_kernel<32>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
+            EDV_LAUNCH(attn_temporal_pixel_kernel<32>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
         else if (lds > 64 * 1024 && T <= 64) {
             EDV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_temporal_pixel_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
-            hipLaunchKernelGGL(attn_temporal_pixel_kernel<64>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
+            EDV_LAUNCH(attn_temporal_pixel_kernel<64>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
         } else if (lds > 64 * 1024) {
             EDV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_temporal_pixel_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
-            hipLaunchKernelGGL(attn_temporal_pixel_kernel<128>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
+            EDV_LAUNCH(attn_temporal_pixel_kernel<128>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
         } else if (T <= 64)  // num_frames > 32 (dpt_temporal.py:35-40 takes any; the reference's scripts keep the default 32)
-            hipLaunchKernelGGL(attn_temporal_pixel_kernel<64>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
+            EDV_LAUNCH(attn_temporal_pixel_kernel<64>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
         else
-            hipLaunchKernelGGL(attn_temporal_pixel_kernel<128>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
+            EDV_LAUNCH(attn_temporal_pixel_kernel<128>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
     } else if (T > 32) {
         EDV_CHECK(false, "temporal attention over more than 32 frames: one head's q|k|v of a pixel (T x 3 x C/8 floats) must fit the 160 KB of LDS");
     } else if (T <= 8 && !per_query) {
         const long long tot = (long long)B * P * heads;
         const dim3 g2((unsigned)((tot + 255) / 256));
         if (T <= 4)
-            hipLaunchKernelGGL(attn_temporal_small_kernel<4>, g2, block, 0, st, qkv, out, B, T, P, C, heads, scale);
+            EDV_LAUNCH(attn_temporal_small_kernel<4>, g2, block, 0, st, qkv, out, B, T, P, C, heads, scale);
         else
-            hipLaunchKernelGGL(attn_temporal_small_kernel<8>, g2, block, 0, st, qkv, out, B, T, P, C, heads, scale);
+            EDV_LAUNCH(attn_temporal_small_kernel<8>, g2, block, 0, st, qkv, out, B, T, P, C, heads, scale);
     } else if (T <= 8)
-        hipLaunchKernelGGL(attn_temporal_kernel<8>, grid, block, 0, st, qkv, out, B, T, P, C, heads, scale);
+        EDV_LAUNCH(attn_temporal_kernel<8>, grid, block, 0, st, qkv, out, B, T, P, C, heads, scale);
     else if (T <= 16)
-        hipLaunchKernelGGL(attn_temporal_kernel<16>, grid, block, 0, st, qkv, out, B, T, P, C, heads, scale);
+        EDV_LAUNCH(attn_temporal_kernel<16>, grid, block, 0, st, qkv, out, B, T, P, C, heads, scale);
     else
-        hipLaunchKernelGGL(attn_temporal_kernel<32>, grid, block, 0, st, qkv, out, B, T, P, C, heads, scale);
+        EDV_LAUNCH(attn_temporal_kernel<32>, grid, block, 0, st, qkv, out, B, T, P, C, heads, scale);
     EDV_LAUNCH_OK();
     return 0;
 }
@@ -303,7 +303,7 @@ int geglu(const float *x, float *y, long long M, int inner, hipStream_t st) {
     EDV_CHECK(M > 0 && inner > 0 && inner % 4 == 0, "shape");
     const long long total4 = M * (inner / 4);
     const int blocks = (int)((total4 + 255) / 256 < 8192 ? (total4 + 255) / 256 : 8192);
-    hipLaunchKernelGGL(geglu_kernel, dim3(blocks), dim3(256), 0, st, x, y, total4, inner / 4);
+    EDV_LAUNCH(geglu_kernel, dim3(blocks), dim3(256), 0, st, x, y, total4, inner / 4);
     EDV_LAUNCH_OK();
     return 0;
 }
@@ -312,7 +312,7 @@ int rope_qk(float *qkv, const float *table, int B, int T, int P, int C, bool tra
     EDV_CHECK(qkv && table, "null operand");
     EDV_CHECK(B > 0 && T > 0 && P > 0 && C > 0 && C % 2 == 0, "bad shape");
     const long long n = (long long)B * T * P * (C / 2);
-    hipLaunchKernelGGL(rope_qk_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, qkv, table, n, T, P, C, transpose ? -1.f : 1.f);
+    EDV_LAUNCH(rope_qk_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, qkv, table, n, T, P, C, transpose ? -1.f : 1.f);
     EDV_LAUNCH_OK();
     return 0;
 }

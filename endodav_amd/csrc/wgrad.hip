@@ -212,10 +212,10 @@ int conv3_wgrad(const float *x, const float *dy, float *dw, int F, int H, int W,
     const long long tasks = (long long)n_rc * n_cg * n_cb;
     EDV_CHECK((size_t)tasks * WG_NB * 1024 <= ws_floats, "conv3_wgrad workspace too small (conv3_wgrad_workspace)");
     EDV_CHECK((tasks + 3) / 4 < (1ll << 31), "grid");
-    hipLaunchKernelGGL(conv3_wgrad_kernel, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, st, x, dy, ws, F, H, W, Cin, Cout, rpt, n_rc, n_cg, tasks);
+    EDV_LAUNCH(conv3_wgrad_kernel, dim3((unsigned)((tasks + 3) / 4)), dim3(256), 0, st, x, dy, ws, F, H, W, Cin, Cout, rpt, n_rc, n_cg, tasks);
     EDV_LAUNCH_OK();
     const int n = Cout * 9 * Cin;
-    hipLaunchKernelGGL(conv3_wgrad_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, st, ws, dw, Cin, Cout, n_rc, n_cg, accumulate ? 1 : 0);
+    EDV_LAUNCH(conv3_wgrad_reduce_kernel, dim3((n + 31) / 32), dim3(256), 0, st, ws, dw, Cin, Cout, n_rc, n_cg, accumulate ? 1 : 0);
     EDV_LAUNCH_OK();
     return 0;
 }
@@ -237,9 +237,9 @@ int colsum_rows(const float *P, const float *rowscale, long long M, int N, float
     const long long total4 = M * n4;
     long long blocks = (total4 + 256 * 8 - 1) / (256 * 8);
     blocks = blocks < 1 ? 1 : (blocks > COLSUM_BLOCKS ? COLSUM_BLOCKS : blocks);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, st, P, rowscale, total4, n4, ws);
+    EDV_LAUNCH(colsum_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, st, P, rowscale, total4, n4, ws);
     EDV_LAUNCH_OK();
-    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 31) / 32), dim3(256), 0, st, ws, (int)blocks, N, fold, accumulate ? 1 : 0, out);
+    EDV_LAUNCH(colsum_reduce_kernel, dim3((N + 31) / 32), dim3(256), 0, st, ws, (int)blocks, N, fold, accumulate ? 1 : 0, out);
     EDV_LAUNCH_OK();
     return 0;
 }

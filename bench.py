@@ -257,8 +257,8 @@ def main():
         # by auto_depth -- 3 at the headline shape, 1 for clips that fill the part alone).  Every step still is one whole forward of one clip,
         # submitted back to back; the closing synchronize of the timed region waits for all of them.  The bracketed steps run one at a time
         # (a bracket must time its kernel alone), after the clips in flight have drained.
-        depth = args.in_flight if args.in_flight > 0 else ClipsInFlight.auto_depth(model, Bc * T)
-        flight = ClipsInFlight(model, dev, depth=depth) if depth > 1 else None
+        n_flight = args.in_flight if args.in_flight > 0 else ClipsInFlight.auto_depth(model, Bc * T)
+        flight = ClipsInFlight(model, dev, depth=n_flight) if n_flight > 1 else None
         handles = []
 
         def step(i):
@@ -269,7 +269,7 @@ def main():
                 model.profile_set(["attn_spatial", "linear"] + list(endodav_amd._lib.HBM_CLASSES))
             if flight is not None and not (events and i >= lin_from):
                 handles.append(flight.submit(x, resident=True))  # x has been in HBM since before the timed region
-                if len(handles) > depth:
+                if len(handles) > n_flight:
                     handles.pop(0)
             else:
                 out["maps"] = model(x)
@@ -360,8 +360,8 @@ def main():
             "config": {"workload": f"ViT-{args.encoder[-1].upper()} endodav (features {kwargs['features']}, out_channels {kwargs['out_channels']}, "
                                    f"{args.lora} r=4, {'conv head' if args.conv_head else 'VDA head'}), {Bc} synthetic {SH}x{SW} T={T} clip(s) per GPU per step "
                                    "(BASELINE.json configs[1] shape at the defaults), hash-initialised weights", "encoder": args.encoder, "T": T,
-                       "image": [SH, SW], "clips_per_gpu_per_step": Bc, "clips_in_flight": depth,
-                       "parallelism": f"clip-sharded x{world}, no data-path collective; {depth} consecutive clip(s) in flight per GPU (one engine context and HIP stream each)"},
+                       "image": [SH, SW], "clips_per_gpu_per_step": Bc, "clips_in_flight": n_flight,
+                       "parallelism": f"clip-sharded x{world}, no data-path collective; {n_flight} consecutive clip(s) in flight per GPU (one engine context and HIP stream each)"},
             "model_tflop_per_clip": round(GFLOP_PER_FRAME[args.encoder] * T / 1e3 * px, 4),
             "model_tflops": round(GFLOP_PER_FRAME[args.encoder] * px * value / 1e3, 2),
             "launches_per_step": model.launch_count(), "device_mem_mb": round(model.device_bytes() / 2 ** 20, 1), "output_finite": finite,

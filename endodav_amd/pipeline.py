@@ -88,6 +88,21 @@ class ClipsInFlight:
         rows = frames * (ph * pw + 1)
         return 3 if rows * model.pretrained.embed_dim <= 22_000 * 384 else 1
 
+    def next_lane(self, frames: int):
+        """(stream, lane id) for the next clip of ``frames`` frames, round-robin: for pipelines that put more than the forward on the lane's stream
+        (``video.HipWindowRunner``: uint8 -> float, pre-resize, forward, resize back).  The caller runs ``model(x, lane=lane)`` under
+        ``torch.cuda.stream(stream)`` and orders its own inputs / outputs with events."""
+        if self.depth is None:
+            self.depth = self.auto_depth(self.model, frames)
+        while len(self.streams) < self.depth:
+            self.streams.append(torch.cuda.Stream(device=self.dev))
+            self.lanes.append(self.model._new_lane())
+            self._ready.append(torch.cuda.Event())
+            self._pool.append([])
+        k = self._k % self.depth
+        self._k += 1
+        return self.streams[k], self.lanes[k]
+
     def submit(self, x: torch.Tensor, resident: bool = False) -> InFlight:
         """Enqueue one clip [B, T, 3, H, W] (device tensor).  ``resident``: the clip's producer finished long ago (a dataset tensor already in HBM),
         so the lane need not wait for the caller's stream."""

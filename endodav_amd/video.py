@@ -115,11 +115,11 @@ def window_sources(n_frames: int) -> List[np.ndarray]:
 
 
 class HipWindowRunner:
-    """Runs 32-frame windows of one video through the HIP forward, pipelined over three streams:
+    """Runs 32-frame windows of one video through the HIP forward, pipelined over copy streams and (round 3) up to three compute lanes:
 
       copy-in stream   window k+1: pinned uint8 frames [32, H, W, 3] -> HBM (2.5 MB .. 126 MB; the whole video is never resident,
                        and nothing is converted to fp32 on the host: the reference ships 4x the bytes, endodav.py:195-197)
-      compute stream   window k: uint8 -> [0, 1] fp32 NCHW, bicubic pre-resize to the network's size (edv_resize_bicubic, replaces the
+      lane streams     window k (and, where a window does not fill the part, k-1, k-2 beside it): uint8 -> [0, 1] fp32 NCHW, bicubic pre-resize to the network's size (edv_resize_bicubic, replaces the
                        host's per-frame cv2.resize), edv_forward, bilinear back to the frame size (edv_bilinear)
       copy-out stream  window k-1: the 32 maps -> pinned host memory in ONE copy (the reference: 32 synchronous .cpu() calls, :205-206)
 
@@ -133,15 +133,27 @@ class HipWindowRunner:
         self.tw, self.th = lower_bound_size(self.fw, self.fh, iw, ih)
 
     def run(self, sources: Sequence[np.ndarray]) -> List[np.ndarray]:
+        from .pipeline import ClipsInFlight
+
         lib = _lib.load()
         dev, fh, fw, th, tw = self.dev, self.fh, self.fw, self.th, self.tw
         if not sources:
             return []
-        nbuf = min(2, len(sources))
         results: List[np.ndarray] = []
         with torch.cuda.device(dev), torch.no_grad():
-            compute = torch.cuda.current_stream(dev)
-            st = C.c_void_p(_lib.stream_ptr(dev))
+            # Round 3: consecutive windows are independent (window_sources), so up to `depth` of them are in flight on the GPU, each on its own
+            # engine context and stream (pipeline.ClipsInFlight; depth by auto_depth: 3 lanes at the reference's 224 x 280, one at 518 x 518 where a
+            # 32-frame window fills the part alone -- ViT-S 224 x 280 T=32: 4140 -> 4380..4760 frames/s, profiles/r03_notes.txt).  A lane's stream
+            # carries the whole per-window chain: uint8 -> float, pre-resize, forward, resize back.
+            depth = ClipsInFlight.auto_depth(self.model, INFER_LEN)
+            flight = getattr(self.model, "_video_flight", None)  # kept with the model: a lane's engine context (packed weights, workspace) is built once
+            if flight is None or flight.dev != dev or flight.depth != depth:
+                flight = ClipsInFlight(self.model, dev, depth=depth)
+                try:
+                    self.model._video_flight = flight
+                except Exception:
+                    pass
+            nbuf = min(depth + 1, len(sources))
             s_in, s_out = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
             h_in = [torch.empty((INFER_LEN, fh, fw, 3), dtype=torch.uint8).pin_memory() for _ in range(nbuf)]
             d_in = [torch.empty((INFER_LEN, fh, fw, 3), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
@@ -158,7 +170,7 @@ class HipWindowRunner:
                 np.take(self.frames, sources[k], axis=0, out=h_in[slot].numpy())
                 with torch.cuda.stream(s_in):
                     if used[slot] is not None:
-                        s_in.wait_event(used[slot])   # window k-2's conversion has read the device buffer
+                        s_in.wait_event(used[slot])   # the conversion of the window that used this slot before has read the device buffer
                     d_in[slot].copy_(h_in[slot], non_blocking=True)
                     up_done[slot] = torch.cuda.Event()
                     up_done[slot].record(s_in)
@@ -173,21 +185,24 @@ class HipWindowRunner:
             for k in range(len(sources)):
                 slot = k % nbuf
                 if k + 1 < len(sources):
-                    upload(k + 1)                     # overlaps window k's forward
-                compute.wait_event(up_done[slot])
-                cur = d_in[slot].permute(0, 3, 1, 2).to(torch.float32).div_(255.0)  # [32, 3, H, W] in [0, 1]
-                used[slot] = torch.cuda.Event()
-                used[slot].record(compute)
-                if (th, tw) != (fh, fw):
-                    small = torch.empty((INFER_LEN, 3, th, tw), device=dev, dtype=torch.float32)
-                    _lib.check(lib.edv_resize_bicubic(cur.data_ptr(), small.data_ptr(), INFER_LEN * 3, fh, fw, th, tw, st), "edv_resize_bicubic")
-                    cur = small
-                disp = self.model(cur.unsqueeze(0))[("disp", 0)]  # [32, 1, ih, iw]
-                drain(slot)                           # frees d_out[slot] / h_out[slot] (window k-2's copy)
-                full = d_out[slot]
-                _lib.check(lib.edv_bilinear(disp.data_ptr(), full.data_ptr(), INFER_LEN, disp.shape[-2], disp.shape[-1], 1, fh, fw, st), "edv_bilinear")
-                ready = torch.cuda.Event()
-                ready.record(compute)
+                    upload(k + 1)                     # overlaps the windows in flight
+                drain(slot)                           # frees d_out[slot] / h_out[slot] (window k - nbuf's copy), in window order
+                stream, lane = flight.next_lane(INFER_LEN)
+                with torch.cuda.stream(stream):
+                    st = C.c_void_p(_lib.stream_ptr(dev))
+                    stream.wait_event(up_done[slot])
+                    cur = d_in[slot].permute(0, 3, 1, 2).to(torch.float32).div_(255.0)  # [32, 3, H, W] in [0, 1]
+                    used[slot] = torch.cuda.Event()
+                    used[slot].record(stream)
+                    if (th, tw) != (fh, fw):
+                        small = torch.empty((INFER_LEN, 3, th, tw), device=dev, dtype=torch.float32)
+                        _lib.check(lib.edv_resize_bicubic(cur.data_ptr(), small.data_ptr(), INFER_LEN * 3, fh, fw, th, tw, st), "edv_resize_bicubic")
+                        cur = small
+                    disp = self.model(cur.unsqueeze(0), lane=lane)[("disp", 0)]  # [32, 1, ih, iw]
+                    full = d_out[slot]
+                    _lib.check(lib.edv_bilinear(disp.data_ptr(), full.data_ptr(), INFER_LEN, disp.shape[-2], disp.shape[-1], 1, fh, fw, st), "edv_bilinear")
+                    ready = torch.cuda.Event()
+                    ready.record(stream)
                 with torch.cuda.stream(s_out):
                     s_out.wait_event(ready)
                     h_out[slot].copy_(full, non_blocking=True)

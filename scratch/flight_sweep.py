@@ -6,11 +6,12 @@ from endodav_amd import synth
 from endodav_amd.pipeline import ClipsInFlight
 dev = torch.device("cuda:0")
 enc = sys.argv[1]; T = int(sys.argv[2]); steps = int(sys.argv[3]) if len(sys.argv) > 3 else 30
+IH, IW = (int(sys.argv[4]), int(sys.argv[5])) if len(sys.argv) > 5 else (518, 518)
 CFG = {"vits": dict(encoder="vits", features=64, out_channels=[48, 96, 192, 384]), "vitb": dict(encoder="vitb", features=128, out_channels=[96, 192, 384, 768]),
        "vitl": dict(encoder="vitl", features=256, out_channels=[256, 512, 1024, 1024])}[enc]
-m = endodav_amd.endodav(**CFG, image_shape=(518, 518), lora_type="dvlora", disable_conv_head=True).eval()
+m = endodav_amd.endodav(**CFG, image_shape=(IH, IW), lora_type="dvlora", disable_conv_head=True).eval()
 synth.fill_module_(m); m = m.to(dev)
-x = torch.from_numpy(synth.synth_clip(1, T, 518, 518, seed=0)).to(dev)
+x = torch.from_numpy(synth.synth_clip(1, T, IH, IW, seed=0)).to(dev)
 with torch.no_grad():
     ref = [o.clone() for o in m(x).values()]
 DEPTHS = (2, 3, 4, 6)
@@ -33,7 +34,7 @@ for rnd in range(3):
     for d in (1,) + DEPTHS:
         torch.cuda.synchronize(); t0 = time.perf_counter(); run(d, steps); torch.cuda.synchronize(); dt = time.perf_counter() - t0
         row.append(f"depth {d}: {steps * T / dt:8.1f}")
-    print(f"{enc} T={T} round {rnd}:  " + "   ".join(row) + "  frames/s", flush=True)
+    print(f"{enc} {IH}x{IW} T={T} round {rnd}:  " + "   ".join(row) + "  frames/s", flush=True)
 hs = [flights[4].submit(x, resident=True) for _ in range(8)]
 bad = 0
 for i, h in enumerate(hs):

@@ -26,7 +26,7 @@ def test_windowing_keyframes_and_stitching_match_reference(cuda):
     frames = (synth.uniform("video:frames", (n, h, w, 3), 0.0, 1.0) * 255).astype(np.uint8)
     seen = []
 
-    def recorder(x):  # same stand-in forward the reference ran when the golden was made
+    def recorder(x, lane=0):  # same stand-in forward the reference ran when the golden was made (lane: which engine context, pipeline.ClipsInFlight)
         assert x.is_cuda and x.shape == (1, 32, 3, h, w)
         seen.append(x[0].mean(dim=(1, 2, 3)).double().cpu().numpy())
         return {("disp", 0): torch.from_numpy(fake_window_disp(len(seen) - 1, h, w)).to(x.device)}

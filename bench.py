@@ -46,7 +46,7 @@ GFLOP_PER_FRAME = {"vits": 121.1, "vitb": 403.9, "vitl": 1403.8}
 LIN_STEPS = 2  # timed steps whose kernels are bracketed with HIP events (see main)
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0         # same guide, "HBM3E peak BW" (spec; 6.29 TB/s measured with a float4 copy)
-PROFILE_ROUND = "r02"         # profiles/<round>_{gemm,attn,hbm}_traffic.json hold the PMC traffic of this round's kernels
+PROFILE_ROUND = "r03"         # profiles/<round>_{gemm,attn,hbm}_traffic.json hold the PMC traffic of this round's kernels
 
 
 def parse():
@@ -82,16 +82,37 @@ def parse():
 
 
 def measured_traffic(encoder, T, image_hw, clips=1, which="gemm"):
-    """HBM-side bytes per launch of a kernel from the committed rocprofv3 --pmc passes (collected in their own runs,
-    FETCH_SIZE doubled as the gfx950 guide prescribes); None when no pass matches this workload."""
-    for rnd in (PROFILE_ROUND, "r01"):
+    """HBM-side bytes per launch of a kernel class from the committed rocprofv3 --pmc passes (collected in their own runs, FETCH_SIZE doubled as the
+    gfx950 guide prescribes); None when no pass matches this workload.  Round 3: profiles/r03_<config>_traffic.json (scratch/evidence_r03.sh) holds every
+    class of one configuration; rounds 1-2 kept one file per class for the headline only."""
+    import glob
+
+    if image_hw[0] != image_hw[1] or clips != 1:
+        return None, None
+    want = {"encoder": encoder, "T": T, "image": image_hw[0]}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_*_traffic.json"))):
+        try:
+            with open(path) as f:
+                rec = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if rec.get("config") != want or "per_class" not in rec:
+            continue
+        pc = rec["per_class"]
+        if which == "gemm" and pc.get("gemm"):
+            return {"traffic_bytes_per_launch": pc["gemm"]["traffic_bytes_per_launch"]}, os.path.relpath(path, ROOT)
+        if which == "attn" and pc.get("attn"):
+            return {"traffic_bytes_per_launch": rec["attn_call_traffic_bytes"]}, os.path.relpath(path, ROOT)
+        if which == "hbm":
+            return {"traffic_bytes_per_launch": {k: (v["traffic_bytes_per_launch"] if v else None) for k, v in pc.items()}}, os.path.relpath(path, ROOT)
+    for rnd in ("r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{which}_traffic.json")
         try:
             with open(path) as f:
                 rec = json.load(f)
         except OSError:
             continue
-        if rec.get("config") == {"encoder": encoder, "T": T, "image": image_hw[0]} and image_hw[0] == image_hw[1] and clips == 1:
+        if rec.get("config") == want:
             return rec, os.path.relpath(path, ROOT)
     return None, None
 
@@ -422,7 +443,7 @@ def train_bench(args, model, x, dev, rank, world, kwargs, rehearsal=False):
 
     def step(i):
         if i == lin_from and events:
-            model.profile_set(["linear"])
+            model.profile_set(["linear", "attn_spatial", "attn_spatial_bwd"] + list(endodav_amd._lib.HBM_CLASSES))
         timed = events and i >= lin_from
         opt.zero_grad(set_to_none=True)
         for t_ in side_leaves:
@@ -445,7 +466,8 @@ def train_bench(args, model, x, dev, rank, world, kwargs, rehearsal=False):
     model(x)  # creates the context
     model.profile_enable([])
     dt, _ = parallel.timed_region(step, args.steps, max(args.warmup, 1), dev)
-    roofline = loss_share = None
+    roofline = loss_share = roofline_hbm = None
+    roofline_attn = {}
     if events:
         n_h, ms_h = model.profile_read("linear")
         fl_h, by_h = model.profile_work("linear")
@@ -459,6 +481,18 @@ def train_bench(args, model, x, dev, rank, world, kwargs, rehearsal=False):
                         "traffic": None, "launches": n_l, "avg_launch_ms": round(ms_l / n_l, 4), "flop_per_launch": round(fl_l / n_l, 1),
                         "algorithmic_bytes_per_launch": round((by_h + by_e) / n_l, 1), "ms_per_step": round(ms_l / LIN_STEPS, 3),
                         "peak_dtype": "f32 MFMA (v_mfma_f32_32x32x2_f32), dense"}
+        D_, depth_, heads_ = DIMS[args.encoder]
+        ntok = (SH // 14) * (SW // 14) + 1
+        fl_att = 4.0 * ntok * ntok * 64 * heads_ * T * args.clips  # forward: QK^T + PV per encoder block
+        for cls_, mult, label in (("attn_spatial", 1.0, "attn_lean_kernel + attn_combine_kernel (forward of one encoder block)"),
+                                  ("attn_spatial_bwd", 3.5, "attn_spatial_bwd_kernel, both passes + combines (backward of one encoder block: seven products against the forward's two)")):
+            n_a, ms_a = model.profile_read(cls_)
+            if n_a > 0 and ms_a > 0:
+                ach = mult * fl_att / (ms_a / n_a * 1e-3) / 1e12
+                roofline_attn[cls_] = {"kernel": label, "bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                       "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "launches": n_a, "avg_launch_ms": round(ms_a / n_a, 4),
+                                       "flop_per_launch": mult * fl_att}
+        roofline_hbm = hbm_roofline(model, args.encoder, T, (SH, SW), args.clips)
         if state.get("ev"):
             fw = [a.elapsed_time(b) for a, b, _ in state["ev"]]
             bw = [b.elapsed_time(c) for _, b, c in state["ev"]]
@@ -482,7 +516,7 @@ def train_bench(args, model, x, dev, rank, world, kwargs, rehearsal=False):
                        "parallelism": f"data-parallel x{world}: one in-place all-reduce of the flat gradient buffer ({state['n']} gradient floats) per step"},
             "trainable_floats": state["n"], "loss": float(state["loss"].item()), "device_mem_mb": round(model.device_bytes() / 2 ** 20, 1),
             "gradients_in_flat_buffer": model.flat_gradients(params) is not None,
-            "roofline": roofline, "loss_share": loss_share, "cpu_baseline": None,
+            "roofline": roofline, "roofline_attention": roofline_attn or None, "roofline_hbm": roofline_hbm, "loss_share": loss_share, "cpu_baseline": None,
         }
         if rehearsal:
             line["rehearsal"] = f"{world} ranks on one GPU: launch-path check, not a scaling number"

@@ -131,7 +131,7 @@ SIGNATURES = {
 # "linear_encoder" (the F.linear launches of the encoder blocks) is recorded whenever "linear" is enabled and read separately;
 # "linear" then holds the remaining F.linear / 1x1-conv launches (patch embed, DPT head)
 KERNEL_CLASSES = {"linear": 0, "conv3x3": 1, "attn_spatial": 2, "attn_temporal": 3, "layernorm": 4, "other": 5, "linear_encoder": 6,
-                  "groupnorm": 7, "bilinear": 8, "geglu": 9, "dot_channels": 10, "patchify": 11}
+                  "groupnorm": 7, "bilinear": 8, "geglu": 9, "dot_channels": 10, "patchify": 11, "attn_spatial_bwd": 12}
 HBM_CLASSES = ("layernorm", "groupnorm", "bilinear", "geglu", "dot_channels", "patchify")  # bandwidth-bound kernels (bench.py roofline_hbm)
 
 

@@ -911,9 +911,16 @@ int attn_temporal_bwd(const float *qkv, const float *dout, float *dqkv, int B, i
     auto lds_of = [&](int hgv) { return ((size_t)T * 4 * hgv * d + (size_t)2 * hgv * T * TM) * sizeof(float); };
     int HG = heads;  // heads per workgroup: as many as fit 256 threads and 64 KB of LDS
     while (HG > 1 && ((long long)T * HG > 256 || lds_of(HG) > 64 * 1024 || heads % HG != 0)) --HG;
-    const bool pixel_fits = d % 4 == 0 && (long long)T * HG <= 256 && lds_of(HG) <= 64 * 1024 && (long long)B * P * (heads / HG) < (1ll << 31);
+    // one head of a wide module at T = 32 needs more than 64 KB (d = 128, ViT-L: 72 KB): the CU has 160.  (Round 2 sent that case to the
+    // one-thread-per-(pixel, head) kernel, whose <32> instantiation spilled 232 VGPRs to scratch; it is gone.)
+    const size_t lds_cap = HG == 1 ? 160 * 1024 : 64 * 1024;
+    const bool pixel_fits = d % 4 == 0 && (long long)T * HG <= 256 && lds_of(HG) <= lds_cap && (long long)B * P * (heads / HG) < (1ll << 31);
     if (pixel_fits && !per_thread) {
         const dim3 g3((unsigned)((long long)B * P * (heads / HG))), b3((unsigned)(((T * HG + 63) / 64) * 64));
+        if (lds_of(HG) > 64 * 1024) {
+            EDV_CHECK(TM == 32, "temporal attention backward: LDS plan");
+            EDV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_temporal_bwd_pixel_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+        }
         if (TM == 8)
             EDV_LAUNCH(attn_temporal_bwd_pixel_kernel<8>, g3, b3, lds_of(HG), st, qkv, dout, dqkv, T, P, C, heads, HG, scale);
         else if (TM == 16)
@@ -925,7 +932,7 @@ int attn_temporal_bwd(const float *qkv, const float *dout, float *dqkv, int B, i
     else if (T <= 16)
         EDV_LAUNCH(attn_temporal_bwd_kernel<16>, grid, block, 0, st, qkv, dout, dqkv, B, T, P, C, heads, scale);
     else
-        EDV_LAUNCH(attn_temporal_bwd_kernel<32>, grid, block, 0, st, qkv, dout, dqkv, B, T, P, C, heads, scale);
+        EDV_CHECK(false, "temporal attention backward at T > 16: one head's rows of a pixel must fit the 160 KB of LDS (head dim <= 272 at T = 32)");
     EDV_LAUNCH_OK();
     return 0;
 }

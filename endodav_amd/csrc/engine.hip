@@ -51,7 +51,7 @@ constexpr int PE_K = 608;  // patch-embed im2col width 3 * 14 * 14 = 588, padded
 // KC_GROUPNORM .. KC_PATCHIFY: the HBM-bound kernels of the forward, each with its algorithmic bytes (tensor in + tensor out, once) for
 // bench.py's roofline_hbm object
 enum { KC_LINEAR = 0, KC_CONV3 = 1, KC_ATTN_SPATIAL = 2, KC_ATTN_TEMPORAL = 3, KC_NORM = 4, KC_OTHER = 5, KC_LINEAR_ENC = 6, KC_GROUPNORM = 7,
-       KC_BILINEAR = 8, KC_GEGLU = 9, KC_DOT = 10, KC_PATCHIFY = 11, KC_COUNT = 12 };
+       KC_BILINEAR = 8, KC_GEGLU = 9, KC_DOT = 10, KC_PATCHIFY = 11, KC_ATTN_SPATIAL_BWD = 12, KC_COUNT = 13 };
 struct EvPool {
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
     size_t used = 0;
@@ -1856,7 +1856,10 @@ struct Run {
             if (i == 0) break;  // nothing trainable below block 0's MLP
             // x_mid = x_in + ls1 * proj(attn(qkv(norm1(x_in))))
             EDV_TRY(dgemm(dxt, MT, D, bp + ".attn.proj", D, t1));
-            EDV_TRY(attn_spatial_bwd(qkv, att, t1, lse, delta, t3, F, ntok, heads, abws, abws_n, st));
+            {
+                Bracket b_(c, KC_ATTN_SPATIAL_BWD, st);  // both passes (dQ; dK, dV) + their combine launches: seven N x N x 64 products per head
+                EDV_TRY(attn_spatial_bwd(qkv, att, t1, lse, delta, t3, F, ntok, heads, abws, abws_n, st));
+            }
             EDV_TRY(dgemm(t3, MT, 3 * D, bp + ".attn.qkv", D, t1));
             EDV_TRY(param(bp + ".norm1.weight", &w2));
             EDV_TRY(layernorm_bwd(x_in, identity_map(), w2, t1, identity_map(), dxt, identity_map(), MT, D, 1e-6f, true, st));
@@ -2037,9 +2040,9 @@ int edv_forward(edv_ctx *ctx, const float *x_dev, int32_t B, int32_t T, int32_t 
     // motion_module.py:197: the position table is sliced to T -> size mismatch beyond num_frames
     EDV_CHECK(T <= ctx->cfg.num_frames, "T exceeds num_frames (temporal_max_len)");
     // The reference takes any T <= num_frames (dpt_temporal.py:35-40, motion_module.py:180-198).  The temporal-attention kernels hold one pixel's
-    // T x T scores on chip: the forward is built up to T = 128 (round 3), the backward up to 32 = the reference's own window length and
+    // T x T scores on chip: the forward is built up to T = 64 (round 3), the backward up to 32 = the reference's own window length and
     // num_frames default (endodav.py:47, :62; its training scripts use T = 16)
-    EDV_CHECK(T <= 128, "T > 128 frames per clip is not built");
+    EDV_CHECK(T <= 64, "T > 64 frames per clip is not built");
     EDV_CHECK(!ctx->train || T <= 32, "a training forward with T > 32 frames per clip is not built (the backward of the temporal attention stops at 32)");
 
     EDV_CHECK((long long)B * T <= 65535, "too many frames in one call");

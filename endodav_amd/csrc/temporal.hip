@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void rope_qk_kernel(float *__restrict__ qkv, c
 int attn_temporal(const float *qkv, float *out, int B, int T, int P, int C, int heads, hipStream_t st) {
     EDV_CHECK(qkv && out, "null operand");
     EDV_CHECK(B > 0 && T > 0 && P > 0 && C > 0 && heads > 0, "empty problem");
-    EDV_CHECK(T <= 128, "T > 128 frames per clip is not built (temporal attention keeps a pixel's T x T scores on chip)");
+    EDV_CHECK(T <= 64, "T > 64 frames per clip is not built (temporal attention keeps a query's T scores in registers)");
     EDV_CHECK(C % heads == 0 && (C / heads) % 4 == 0, "head dim must be a multiple of 4");
     const long long total = (long long)B * T * P * heads;
     const long long blocks = (total + 255) / 256;
@@ -269,16 +269,11 @@ int attn_temporal(const float *qkv, float *out, int B, int T, int P, int C, int 
             EDV_LAUNCH(attn_temporal_pixel_kernel<16>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
         else if (T <= 32)
             EDV_LAUNCH(attn_temporal_pixel_kernel<32>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
-        else if (lds > 64 * 1024 && T <= 64) {
-            EDV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_temporal_pixel_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
+        else {  // 32 < T <= 64: num_frames > 32 (dpt_temporal.py:35-40 takes any; the reference's scripts keep the default 32)
+            if (lds > 64 * 1024)
+                EDV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_temporal_pixel_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
             EDV_LAUNCH(attn_temporal_pixel_kernel<64>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
-        } else if (lds > 64 * 1024) {
-            EDV_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(attn_temporal_pixel_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_cap));
-            EDV_LAUNCH(attn_temporal_pixel_kernel<128>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
-        } else if (T <= 64)  // num_frames > 32 (dpt_temporal.py:35-40 takes any; the reference's scripts keep the default 32)
-            EDV_LAUNCH(attn_temporal_pixel_kernel<64>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
-        else
-            EDV_LAUNCH(attn_temporal_pixel_kernel<128>, g3, b3, lds, st, qkv, out, T, P, C, heads, HG, scale);
+        }
     } else if (T > 32) {
         EDV_CHECK(false, "temporal attention over more than 32 frames: one head's q|k|v of a pixel (T x 3 x C/8 floats) must fit the 160 KB of LDS");
     } else if (T <= 8 && !per_query) {

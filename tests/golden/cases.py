@@ -28,7 +28,6 @@ CASES = {
     "micro_t32": (dict(VITS_SMALL_HEAD, image_shape=(42, 42), lora_type="dvlora", disable_conv_head=True), (1, 32, 42, 42), "tissue", "full"),
     # num_frames > 32 (the constructor takes any, dpt_temporal.py:35-40; the reference's scripts keep 32): clips longer than one 32-frame window
     "micro_t48": (dict(VITS_SMALL_HEAD, image_shape=(42, 42), lora_type="dvlora", disable_conv_head=True, num_frames=64), (1, 48, 42, 42), "tissue", "full"),
-    "micro_t80": (dict(VITS_SMALL_HEAD, image_shape=(28, 42), lora_type="lora", disable_conv_head=True, num_frames=96), (1, 80, 28, 42), "tissue", "full"),
     "micro_vitl": (dict(VITL_SMALL_HEAD, image_shape=(42, 56), lora_type="dvlora", disable_conv_head=True), (1, 2, 42, 56), "uniform", "full"),
     # --- options no reference script sets, still part of the constructor surface --------------------------
     "micro_clstoken": (dict(VITS_SMALL_HEAD, image_shape=(42, 56), lora_type="dvlora", disable_conv_head=True, use_clstoken=True), (1, 2, 42, 56), "uniform", "full"),

@@ -316,7 +316,7 @@ def test_errors_are_loud(cuda):
             model(torch.rand(1, 33, 3, 42, 56, device=cuda))
     with pytest.raises(KeyError):
         endodav_amd.endodav(encoder="vitx")
-    long_model = endodav_amd.endodav(**{**kwargs, "num_frames": 48}).to(cuda).train()  # num_frames > 32: inference is built (goldens micro_t48 / micro_t80),
+    long_model = endodav_amd.endodav(**{**kwargs, "num_frames": 48}).to(cuda).train()  # num_frames > 32: inference is built up to 64 frames (golden micro_t48),
     endodav_amd.mark_only_part_as_trainable(long_model, warm_up=True)                     # a training forward beyond 32 frames is refused, not mis-differentiated
     with pytest.raises(RuntimeError, match="32"):
         long_model(torch.rand(1, 40, 3, 42, 56, device=cuda))

@@ -395,7 +395,7 @@ def test_attn_spatial_peaked_rows(lib, cuda):
 @pytest.mark.parametrize("Bc,T,P,Cc", [(1, 8, 37 * 37, 192), (2, 3, 50, 64), (1, 16, 19 * 19, 384), (1, 32, 41, 32), (1, 1, 9, 64), (2, 32, 30, 256),
                                        (1, 8, 19 * 19, 384), (2, 5, 100, 192), (1, 8, 74 * 74, 64), (3, 4, 77, 64), (1, 1, 33, 384),
                                        (1, 16, 19 * 19, 768), (1, 16, 300, 128), (1, 32, 100, 1024), (1, 32, 200, 256), (2, 12, 50, 512),
-                                       (1, 48, 40, 64), (1, 64, 25, 192), (2, 80, 9, 32), (1, 128, 7, 256), (1, 100, 13, 1024)])  # round 3: num_frames > 32
+                                       (1, 48, 40, 64), (1, 64, 25, 192), (2, 40, 9, 32), (1, 64, 7, 256), (1, 56, 13, 1024)])  # round 3: num_frames > 32
 def test_attn_temporal(lib, cuda, Bc, T, P, Cc):
     heads, d = 8, Cc // 8
     qkv = rnd(Bc * T * P, 3 * Cc, seed=1, scale=1.5)
@@ -436,10 +436,10 @@ def test_rope_qk(lib, cuda, Bc, T, P, Cc):
     close(qd, qkv, 1e-6, "rope round trip")
 
 
-def test_attn_temporal_rejects_clips_beyond_128_frames(lib, cuda):
-    z = torch.zeros(129 * 8 * 3 * 64, device=cuda)
-    assert lib.edv_attn_temporal(z.data_ptr(), z.data_ptr(), 1, 129, 8, 64, 8, st()) != 0
-    assert b"128" in lib.edv_last_error()
+def test_attn_temporal_rejects_clips_beyond_64_frames(lib, cuda):
+    z = torch.zeros(65 * 8 * 3 * 64, device=cuda)
+    assert lib.edv_attn_temporal(z.data_ptr(), z.data_ptr(), 1, 65, 8, 64, 8, st()) != 0
+    assert b"64" in lib.edv_last_error()
 
 
 # ----------------------------------------------------------------------------------------------

@@ -43,7 +43,7 @@ MODELS = {"vits": VITS, "vitb": VITB, "vitl": VITL}
 DIMS = {"vits": (384, 12, 6), "vitb": (768, 12, 12), "vitl": (1024, 24, 16)}
 # matmul+conv FLOPs per 518x518 frame, FlopCounterMode over the reference
 GFLOP_PER_FRAME = {"vits": 121.1, "vitb": 403.9, "vitl": 1403.8}
-LIN_STEPS = 2  # timed steps whose kernels are bracketed with HIP events (see main)
+LIN_STEPS = 2  # timed steps (the first ones) whose kernels are bracketed with HIP events (see main)
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0         # same guide, "HBM3E peak BW" (spec; 6.29 TB/s measured with a float4 copy)
 PROFILE_ROUND = "r03"         # profiles/<round>_{gemm,attn,hbm}_traffic.json hold the PMC traffic of this round's kernels
@@ -154,7 +154,7 @@ def cpu_baseline(kwargs, T, image_hw, threads):
 
 
 def hbm_roofline(model, encoder, T, image_hw, clips):
-    """Bandwidth-bound kernel classes bracketed in the last LIN_STEPS steps: algorithmic bytes / launch time against the HBM peak."""
+    """Bandwidth-bound kernel classes bracketed in LIN_STEPS steps of the timed region: algorithmic bytes / launch time against the HBM peak."""
     from endodav_amd import _lib
 
     rec, src = measured_traffic(encoder, T, image_hw, clips, "hbm")
@@ -268,27 +268,27 @@ def main():
         model(x)  # creates the context (profile_* need one)
         if events:
             model.profile_enable([])
-        # Kernel timing happens inside the timed region, in its last LIN_STEPS steps: there every dense-GEMM launch, every attention call
-        # and every bandwidth-bound kernel is bracketed with a HIP event pair on its launch stream, and the encoder runs single-stream so
-        # that a bracket times the kernel alone (one stream is the engine's default since round 2; the head's side stream is joined around
-        # every bracket).  Those steps run a few per cent slower than the others (~300 event pairs).
-        lin_from = args.steps - min(LIN_STEPS, args.steps)
+        # Kernel timing happens inside the timed region, in its FIRST LIN_STEPS steps: there every dense-GEMM launch, every attention call and every
+        # bandwidth-bound kernel carries a HIP event pair inside its dispatch (edv_profile_enable: kernel start -> kernel end, the interval rocprofv3
+        # reports), one clip at a time and the encoder on one stream, so that a bracket times its kernel alone.  From step LIN_STEPS on the brackets
+        # are off and consecutive clips are in flight: they are independent, so the engine keeps several going (pipeline.ClipsInFlight: one context +
+        # stream per lane, depth by auto_depth -- 3 at the headline shape, 1 for clips that fill the part alone).  Every step still is one whole
+        # forward of one clip, submitted back to back; the closing synchronize of the timed region waits for all of them.  (Rounds 1-2 bracketed
+        # the LAST steps; with clips in flight that needs a drain in the middle of the timed region, the first steps start from an idle GPU anyway.)
+        lin_to = min(LIN_STEPS, args.steps) if events else 0
         out = {}
-        # Consecutive clips are independent, so the engine keeps several in flight (pipeline.ClipsInFlight: one context + stream per lane, depth
-        # by auto_depth -- 3 at the headline shape, 1 for clips that fill the part alone).  Every step still is one whole forward of one clip,
-        # submitted back to back; the closing synchronize of the timed region waits for all of them.  The bracketed steps run one at a time
-        # (a bracket must time its kernel alone), after the clips in flight have drained.
         n_flight = args.in_flight if args.in_flight > 0 else ClipsInFlight.auto_depth(model, Bc * T)
         flight = ClipsInFlight(model, dev, depth=n_flight) if n_flight > 1 else None
         handles = []
 
         def step(i):
-            if i == lin_from and events:
-                if flight is not None:
-                    torch.cuda.synchronize(dev)
+            if events and i == 0:
                 model.set_encoder_streams(1)
                 model.profile_set(["attn_spatial", "linear"] + list(endodav_amd._lib.HBM_CLASSES))
-            if flight is not None and not (events and i >= lin_from):
+            if events and i == lin_to:
+                model.profile_set([])  # what was recorded stays
+                model.set_encoder_streams(-1)
+            if flight is not None and not (0 <= i < lin_to):
                 handles.append(flight.submit(x, resident=True))  # x has been in HBM since before the timed region
                 if len(handles) > n_flight:
                     handles.pop(0)
@@ -296,15 +296,14 @@ def main():
                 out["maps"] = model(x)
 
         dt, _ = parallel.timed_region(step, args.steps, max(args.warmup, 1), dev)
-        if events:
+        if events and args.steps <= lin_to:
+            model.profile_set([])
             model.set_encoder_streams(-1)
-        if "maps" not in out:
+        if handles:
             out["maps"] = handles[-1].result()
         serial_value = None
         if flight is not None:  # the same steps one clip at a time (reported beside `value`, never as it)
             n_s = max(args.steps // 2, 4)
-            if events:
-                model.profile_set([])  # no brackets in these steps (what was recorded stays)
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
             for _ in range(n_s):

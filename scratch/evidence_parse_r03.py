@@ -46,7 +46,7 @@ def arg(flag, default):
 
 cfg = {"encoder": arg("--encoder", "vits"), "T": int(arg("--T", "8")), "image": int(str(arg("--image", "518")).split("x")[0])}
 out = {"config": cfg, "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (two separate passes) --kernel-trace --output-format csv -- python3 bench.py --no-cpu-baseline "
-       "--no-kernel-events --in-flight 1 --steps 4 --warmup 2 " + " ".join(args),
+       "--no-kernel-events --in-flight 1 --steps 4 --warmup 2 (after: " + " ".join(args) + ")",
        "correction": "gfx950: FETCH_SIZE counts 128-B requests at 64 B for wide coalesced reads (MI355X_MICROARCH.md, HBM) -> doubled; WRITE_SIZE exact; counter unit KB",
        "per_class": {k: per_launch(k) for k in ("gemm", "attn", "attn_combine", "conv3x3", "layernorm", "groupnorm", "bilinear", "geglu", "dot_channels", "patchify", "attn_temporal")}}
 g, a, ac = out["per_class"]["gemm"], out["per_class"]["attn"], out["per_class"]["attn_combine"]
@@ -55,26 +55,32 @@ out["attn_call_traffic_bytes"] = (a["traffic_bytes_per_launch"] + (ac["traffic_b
 json.dump(out, open(f"{O}/{name}_traffic.json", "w"), indent=1)
 
 # ---- MFMA-pipe utilisation ----
+def short(kn):
+    kn = kn.replace("void ", "").replace("edv::(anonymous namespace)::", "")
+    depth = 0
+    for i, ch in enumerate(kn):  # cut the argument list: the first "(" outside the template brackets
+        if ch == "<": depth += 1
+        elif ch == ">": depth -= 1
+        elif ch == "(" and depth == 0:
+            return kn[:i]
+    return kn
+
+
 rows = collections.defaultdict(lambda: collections.defaultdict(float))
 calls = collections.Counter()
 for fn in glob.glob(f"{O}/pmc_{name}_mfma/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(fn)):
-        kn = r["Kernel_Name"]
-        key = kn[:kn.index("(")] if "(" in kn else kn
-        key = key.replace("void edv::(anonymous namespace)::", "").replace("edv::(anonymous namespace)::", "")
+        key = short(r["Kernel_Name"])
         rows[key][r["Counter_Name"]] += float(r["Counter_Value"])
         if r["Counter_Name"] == "SQ_BUSY_CYCLES":
             calls[key] += 1
 dur = collections.defaultdict(float)
 for fn in glob.glob(f"{O}/pmc_{name}_mfma/**/*kernel_trace.csv", recursive=True):
     for r in csv.DictReader(open(fn)):
-        kn = r["Kernel_Name"]
-        key = kn[:kn.index("(")] if "(" in kn else kn
-        key = key.replace("void edv::(anonymous namespace)::", "").replace("edv::(anonymous namespace)::", "")
-        dur[key] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
+        dur[short(r["Kernel_Name"])] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-9
 with open(f"{O}/{name}_mfma_busy.txt", "w") as f:
     f.write(f"MFMA-pipe utilisation by counters, {name}: one rocprofv3 --pmc pass (SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE) of\n"
-            f"python3 bench.py --no-cpu-baseline --no-kernel-events --in-flight 1 --steps 4 --warmup 2 {' '.join(args)}\n"
+            f"python3 bench.py {' '.join(args)} --no-cpu-baseline --no-kernel-events --in-flight 1 --steps 4 --warmup 2\n"
             "busy/SQ   = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CYCLES x 32)        (share of the time a SIMD had waves in which its matrix pipe was executing)\n"
             "busy/wall = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)  (share of the launch's whole duration, ramp and tail included)\n"
             "clock     = GRBM_GUI_ACTIVE / 8 / kernel duration (reads high on launches under ~0.3 ms: MI355X_MICROARCH.md, DVFS give-back)\n\n")

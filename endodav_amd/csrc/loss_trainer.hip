@@ -225,14 +225,15 @@ __global__ __launch_bounds__(256) void cvt_kernel(const float *__restrict__ tr, 
     if (threadIdx.x == 0) part[(long long)f * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
 }
 
-// sums of the mask the normalisations need: out[0] = sum m, out[1] = sum m[:, :, :, :-1], out[2] = sum m[:, :, :-1, :]   (one workgroup per frame, then one wave)
+// sums of the mask the normalisations need: out[0] = sum m, out[1] = sum m[:, :, :, :-1], out[2] = sum m[:, :, :-1, :]   (MASK_BLOCKS workgroups per frame, then one wave)
+constexpr int MASK_BLOCKS = 32;
 __global__ __launch_bounds__(256) void mask_sums_kernel(const float *__restrict__ mask, float *__restrict__ part, int H, int W) {
     __shared__ float red[3][4];
-    const int f = blockIdx.x;
+    const int f = blockIdx.y;
     const long long P = (long long)H * W;
     const float *m = mask + (long long)f * P;
     float a = 0.f, bx = 0.f, by = 0.f;
-    for (long long p = threadIdx.x; p < P; p += 256) {
+    for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p < P; p += (long long)MASK_BLOCKS * 256) {
         const int y = (int)(p / W), x = (int)(p - (long long)y * W);
         const float v = m[p];
         a += v;
@@ -246,17 +247,38 @@ __global__ __launch_bounds__(256) void mask_sums_kernel(const float *__restrict_
         if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = s;
     }
     __syncthreads();
-    if (threadIdx.x < 3) part[f * 3 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+    if (threadIdx.x < 3) part[((long long)f * MASK_BLOCKS + blockIdx.x) * 3 + threadIdx.x] = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
 }
-__global__ __launch_bounds__(64) void mask_sums_finish_kernel(const float *__restrict__ part, float *__restrict__ out, int N) {
+__global__ __launch_bounds__(64) void mask_sums_finish_kernel(const float *__restrict__ part, float *__restrict__ out, int n) {
     float a = 0.f, b = 0.f, c = 0.f;
-    for (int f = threadIdx.x; f < N; f += 64) {
+    for (int f = threadIdx.x; f < n; f += 64) {
         a += part[f * 3];
         b += part[f * 3 + 1];
         c += part[f * 3 + 2];
     }
     a = wave_sum(a); b = wave_sum(b); c = wave_sum(c);
     if (threadIdx.x == 0) { out[0] = a; out[1] = b; out[2] = c; }
+}
+
+// x *= a over a list of tensors in one launch (blockIdx.y = tensor)
+constexpr int SCALE_LIST = 32;
+struct ScaleList {
+    float *p[SCALE_LIST];
+    long long n[SCALE_LIST];
+};
+__global__ __launch_bounds__(256) void scale_list_kernel(ScaleList l, float a) {
+    float *p = l.p[blockIdx.y];
+    const long long n = l.n[blockIdx.y];
+    if ((n & 3) == 0 && ((uintptr_t)p & 15) == 0) {
+        float4 *p4 = reinterpret_cast<float4 *>(p);
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (long long)gridDim.x * 256) {
+            float4 v = p4[i];
+            v.x *= a; v.y *= a; v.z *= a; v.w *= a;
+            p4[i] = v;
+        }
+    } else {
+        for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) p[i] *= a;
+    }
 }
 
 // ---- depth-consistency terms ---------------------------------------------------------------------------------------------------------------------------
@@ -534,39 +556,44 @@ __global__ __launch_bounds__(256) void add_kernel(const float *__restrict__ a, f
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] += a[i];
 }
 
-// per frame: dP[nb] (3x4) and d iK (3x3) from the block partials; dK += dP T^T (rows 0..2), dT += K[:3, :]^T dP, d inv_K[:3, :3] += d iK.  One thread per frame.
-__global__ void pose_finish_kernel(const float *__restrict__ pose_part, int blocks, const float *__restrict__ K, const float *__restrict__ Tp, const float *__restrict__ Tn,
+// per frame: dP[nb] (3x4) and d iK (3x3) from the block partials; dK += dP T^T (rows 0..2), dT += K[:3, :]^T dP, d inv_K[:3, :3] += d iK.  One wave per frame:
+// lane k < 33 sums partial k over the blocks (in block order), then 12 + 16 + 16 + 9 lanes write one output element each.
+__global__ __launch_bounds__(64) void pose_finish_kernel(const float *__restrict__ pose_part, int blocks, const float *__restrict__ K, const float *__restrict__ Tp, const float *__restrict__ Tn,
                                    float *__restrict__ gK, float *__restrict__ gInvK, float *__restrict__ gTp, float *__restrict__ gTn, int N) {
-    const int f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= N) return;
-    float s[33];
-    for (int k = 0; k < 33; ++k) {
+    __shared__ float s[33];
+    const int f = blockIdx.x, t = threadIdx.x;
+    if (t < 33) {
         float a = 0.f;
-        for (int b = 0; b < blocks; ++b) a += pose_part[((long long)f * blocks + b) * 33 + k];
-        s[k] = a;
+        for (int b = 0; b < blocks; ++b) a += pose_part[((long long)f * blocks + b) * 33 + t];
+        s[t] = a;
     }
+    __syncthreads();
     const float *k4 = K + (long long)f * 16;
-    for (int nb = 0; nb < 2; ++nb) {
-        const float *dP = s + nb * 12, *T = (nb ? Tn : Tp) + (long long)f * 16;
-        float *gT = (nb ? gTn : gTp);
-        if (gK)
-            for (int r = 0; r < 3; ++r)
-                for (int j = 0; j < 4; ++j) {  // dK[r][j] = sum_c dP[r][c] T[j][c]
-                    float a = 0.f;
-                    for (int c = 0; c < 4; ++c) a += dP[r * 4 + c] * T[j * 4 + c];
-                    gK[(long long)f * 16 + r * 4 + j] += a;
-                }
-        if (gT)
-            for (int j = 0; j < 4; ++j)
-                for (int c = 0; c < 4; ++c) {  // dT[j][c] = sum_r K[r][j] dP[r][c]
-                    float a = 0.f;
-                    for (int r = 0; r < 3; ++r) a += k4[r * 4 + j] * dP[r * 4 + c];
-                    gT[(long long)f * 16 + j * 4 + c] += a;
-                }
+    if (gK && t < 12) {  // dK[r][j] = sum over the neighbours (previous first) and c of dP[r][c] T[j][c]
+        const int r = t >> 2, j = t & 3;
+        float tot = gK[(long long)f * 16 + t];
+        for (int nb = 0; nb < 2; ++nb) {
+            const float *dP = s + nb * 12, *T = (nb ? Tn : Tp) + (long long)f * 16;
+            float a = 0.f;
+            for (int c = 0; c < 4; ++c) a += dP[r * 4 + c] * T[j * 4 + c];
+            tot += a;
+        }
+        gK[(long long)f * 16 + t] = tot;
     }
-    if (gInvK)
-        for (int a = 0; a < 3; ++a)
-            for (int b = 0; b < 3; ++b) gInvK[(long long)f * 16 + a * 4 + b] += s[24 + a * 3 + b];
+    if (t >= 16 && t < 48) {  // dT[j][c] = sum_r K[r][j] dP[r][c]
+        const int nb = (t - 16) >> 4, e = (t - 16) & 15, j = e >> 2, c = e & 3;
+        float *gT = nb ? gTn : gTp;
+        if (gT) {
+            const float *dP = s + nb * 12;
+            float a = 0.f;
+            for (int r = 0; r < 3; ++r) a += k4[r * 4 + j] * dP[r * 4 + c];
+            gT[(long long)f * 16 + e] += a;
+        }
+    }
+    if (gInvK && t >= 48 && t < 57) {
+        const int e = t - 48, a = e / 3, b = e - a * 3;
+        gInvK[(long long)f * 16 + a * 4 + b] += s[24 + e];
+    }
 }
 
 // One workgroup: this scale's terms -> losses[s * 7 + ...] and the running total; S[f] for the smoothness gradient
@@ -627,7 +654,7 @@ __global__ __launch_bounds__(256) void finish_scale_kernel(FinishArgs a, float *
 struct TLWs {  // carve-up of the caller's workspace (floats)
     size_t cams, msum, mpart, D, Dc, mean, S, sum_part, sm_part, ssim_part[2], cvt_part[2], pair_part, drp_tot, dfl_tot, gsm, gDc, gD, gdg, gdep, xw, gx, pose_part, total;
 };
-constexpr int SM_BLOCKS = 64, CVT_BLOCKS = 64, PAIR_BLOCKS = 64, POSE_BLOCKS = 32;
+constexpr int SM_BLOCKS = 64, CVT_BLOCKS = 64, PAIR_BLOCKS = 64, POSE_BLOCKS = 128;
 TLWs tl_layout(int N, int H, int W) {
     const size_t P = (size_t)H * W;
     const size_t tiles = (size_t)((H + TS - 1) / TS) * ((W + TS - 1) / TS);
@@ -636,7 +663,7 @@ TLWs tl_layout(int N, int H, int W) {
     size_t o = 0;
     w.cams = o; o += up(2 * (size_t)N * (sizeof(Cam) / sizeof(float)));
     w.msum = o; o += up(2 * 4);
-    w.mpart = o; o += up((size_t)N * 3);
+    w.mpart = o; o += up((size_t)N * MASK_BLOCKS * 3);
     w.D = o; o += up((size_t)N * P);
     w.Dc = o; o += up((size_t)N * P);
     w.mean = o; o += up(N);
@@ -693,9 +720,9 @@ int trainer_loss(const TrainerLossIn &in, int N, int H, int W, const TrainerLoss
     EDV_LAUNCH(cam_kernel, dim3((2 * N + 63) / 64), dim3(64), 0, st, in.K, in.invK, in.T[0], in.T[1], cams, N);
     EDV_LAUNCH_OK();
     for (int nb = 0; nb < 2; ++nb) {
-        EDV_LAUNCH(mask_sums_kernel, dim3(N), dim3(256), 0, st, in.mask[nb], mpart, H, W);
+        EDV_LAUNCH(mask_sums_kernel, dim3(MASK_BLOCKS, N), dim3(256), 0, st, in.mask[nb], mpart, H, W);
         EDV_LAUNCH_OK();
-        EDV_LAUNCH(mask_sums_finish_kernel, dim3(1), dim3(64), 0, st, mpart, msum + nb * 4, N);
+        EDV_LAUNCH(mask_sums_finish_kernel, dim3(1), dim3(64), 0, st, mpart, msum + nb * 4, N * MASK_BLOCKS);
         EDV_LAUNCH_OK();
     }
     for (int s = 0; s < 4; ++s) {
@@ -788,28 +815,36 @@ int trainer_loss(const TrainerLossIn &in, int N, int H, int W, const TrainerLoss
             EDV_TRY(bilinear_bwd(gDc, g.disp[s], N, in.disp_h[s], in.disp_w[s], 1, Hc, Wc, true, st));
         }
         if (pose) {
-            EDV_LAUNCH(pose_finish_kernel, dim3((N + 63) / 64), dim3(64), 0, st, pose_part, gb, in.K, in.T[0], in.T[1], g.K, g.invK, g.T[0], g.T[1], N);
+            EDV_LAUNCH(pose_finish_kernel, dim3(N), dim3(64), 0, st, pose_part, gb, in.K, in.T[0], in.T[1], g.K, g.invK, g.T[0], g.T[1], N);
             EDV_LAUNCH_OK();
         }
     }
     // the mean over the four scales (trainer :968): every gradient written above is d(loss_s); scale them by 1/4
-    auto scale = [&](float *p, long long n) -> int {
-        if (!p) return 0;
-        EDV_LAUNCH(scale_kernel, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0, st, p, n, 0.25f);
-        EDV_LAUNCH_OK();
-        return 0;
+    ScaleList sl;
+    int ns = 0;
+    long long nmax = 0;
+    auto scale = [&](float *p, long long n) {
+        if (!p || n <= 0) return;
+        sl.p[ns] = p;
+        sl.n[ns++] = n;
+        nmax = n > nmax ? n : nmax;
     };
     for (int s = 0; s < 4; ++s) {
-        EDV_TRY(scale(g.disp[s], (long long)N * in.disp_h[s] * in.disp_w[s]));
+        scale(g.disp[s], (long long)N * in.disp_h[s] * in.disp_w[s]);
         for (int nb = 0; nb < 2; ++nb) {
-            EDV_TRY(scale(g.refined[s][nb], (long long)N * 3 * P));
-            EDV_TRY(scale(g.transform[s][nb], (long long)N * 3 * P));
+            scale(g.refined[s][nb], (long long)N * 3 * P);
+            scale(g.transform[s][nb], (long long)N * 3 * P);
         }
     }
-    EDV_TRY(scale(g.K, (long long)N * 16));
-    EDV_TRY(scale(g.invK, (long long)N * 16));
-    EDV_TRY(scale(g.T[0], (long long)N * 16));
-    EDV_TRY(scale(g.T[1], (long long)N * 16));
+    scale(g.K, (long long)N * 16);
+    scale(g.invK, (long long)N * 16);
+    scale(g.T[0], (long long)N * 16);
+    scale(g.T[1], (long long)N * 16);
+    static_assert(4 * 5 + 4 <= SCALE_LIST, "scale list");
+    for (int i = ns; i < SCALE_LIST; ++i) { sl.p[i] = nullptr; sl.n[i] = 0; }
+    const long long b4 = (nmax / 4 + 255) / 256;
+    EDV_LAUNCH(scale_list_kernel, dim3((unsigned)(b4 < 1 ? 1 : b4 > 256 ? 256 : b4), ns), dim3(256), 0, st, sl, 0.25f);
+    EDV_LAUNCH_OK();
     return 0;
 }
 

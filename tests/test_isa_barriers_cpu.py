@@ -69,3 +69,19 @@ def test_no_lds_traffic_in_flight_across_any_barrier(kernels):
         if v:
             bad[name] = v
     assert not bad, "\n".join(f"{n}: {v}" for n, v in bad.items())
+
+
+def test_store_hazard_checker_on_hand_made_listings():
+    st = I("buffer_store_dwordx4", "v[8:11], v4, s[0:3], s6 offen")
+    assert len(isa.store_hazard_violations([st, I("v_mov_b32_e32", "v8, v20")])) == 1                    # the failing form of the microbenchmark
+    assert len(isa.store_hazard_violations([st, I("s_add_u32", "s6, s6, s7"), I("v_add_f32_e32", "v11, v1, v2")])) == 1   # one wait state is not two
+    assert isa.store_hazard_violations([st, I("s_nop", "3"), I("v_mov_b32_e32", "v8, v20")]) == []
+    assert isa.store_hazard_violations([st, I("v_mov_b32_e32", "v12, v20"), I("v_mov_b32_e32", "v13, v20"), I("v_mov_b32_e32", "v8, v20")]) == []
+    # the immediate form is the compiler's business (it pads it), and a 64-bit store has no such hazard
+    assert isa.store_hazard_violations([I("buffer_store_dwordx4", "v[8:11], v4, s[0:3], 0 offen"), I("v_mov_b32_e32", "v8, v20")]) == []
+    assert isa.store_hazard_violations([I("buffer_store_dwordx2", "v[8:9], v4, s[0:3], s6 offen"), I("v_mov_b32_e32", "v8, v20")]) == []
+
+
+def test_no_wide_store_with_register_soffset_is_followed_by_a_write_of_its_data(kernels):
+    bad = {n: v for n, v in ((n, isa.store_hazard_violations(i)) for n, i in kernels.items()) if v}
+    assert not bad, "\n".join(f"{n}: {v}" for n, v in bad.items())

@@ -3,7 +3,7 @@ HIPCC    ?= /opt/rocm/bin/hipcc
 ARCH     ?= gfx950
 CSRC     := endodav_amd/csrc
 OUT      := endodav_amd/lib/libendodav_hip.so
-SRCS     := $(CSRC)/gemm.hip $(CSRC)/gemm_dma.hip $(CSRC)/conv_dma.hip $(CSRC)/attn_spatial.hip $(CSRC)/attn_spatial_bwd.hip $(CSRC)/norms.hip $(CSRC)/temporal.hip \
+SRCS     := $(CSRC)/gemm.hip $(CSRC)/gemm_dma.hip $(CSRC)/gemm_x6.hip $(CSRC)/conv_dma.hip $(CSRC)/attn_spatial.hip $(CSRC)/attn_spatial_bwd.hip $(CSRC)/norms.hip $(CSRC)/temporal.hip \
             $(CSRC)/resample.hip $(CSRC)/prep.hip $(CSRC)/bwd.hip $(CSRC)/wgrad.hip $(CSRC)/loss.hip $(CSRC)/loss_trainer.hip $(CSRC)/engine.hip $(CSRC)/api.hip
 OBJS     := $(SRCS:$(CSRC)/%.hip=build/%.o)
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++20 -fPIC -Wall -Wno-unused-function -fno-gpu-rdc

@@ -11,7 +11,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("EDV_LIB_PATH") or os.path.join(_HERE, "lib", "libendodav_hip.so")  # override: experiments only
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 LORA_TYPES = {"none": 0, "lora": 1, "dvlora": 2, "ssb": 3, "dash": 4}
 ACT_NONE, ACT_GELU, ACT_RELU, ACT_SIGMOID, ACT_SIGMOID_NEG = 0, 1, 2, 3, 4
@@ -65,6 +65,8 @@ SIGNATURES = {
     "edv_set_capture": (C.c_int, [C.c_void_p, C.c_int]),
     "edv_profile_enable": (C.c_int, [C.c_void_p, C.c_uint32]),
     "edv_set_encoder_streams": (C.c_int, [C.c_void_p, _i32]),
+    "edv_set_products": (C.c_int, [C.c_void_p, _i32, C.c_void_p]),
+    "edv_get_products": (C.c_int, [C.c_void_p]),
     "edv_profile_set_mask": (C.c_int, [C.c_void_p, C.c_uint32]),
     "edv_profile_work": (C.c_int, [C.c_void_p, _i32, C.POINTER(_f64), C.POINTER(_f64)]),
     "edv_profile_read": (C.c_int, [C.c_void_p, _i32, C.POINTER(_i32), C.POINTER(_f64)]),
@@ -72,6 +74,9 @@ SIGNATURES = {
     "edv_last_launch_count": (C.c_int, [C.c_void_p]),
     "edv_layernorm": (C.c_int, [_fp, _fp, _fp, _fp, _i64, _i32, _f32, _fp, _i32, _i32, C.c_void_p]),
     "edv_gemm_workspace": (C.c_size_t, []),
+    "edv_gemm_x6_planes_bytes": (C.c_size_t, [_i32, _i32]),
+    "edv_gemm_x6_split": (C.c_int, [_fp, C.c_void_p, _i32, _i32, C.c_void_p]),
+    "edv_gemm_x6": (C.c_int, [_fp, C.c_void_p, _fp, _i64, _i32, _i32, _fp, _i32, _fp, _fp, _fp, C.c_size_t, C.c_void_p]),
     "edv_gemm": (C.c_int, [_fp, _fp, _fp, _i64, _i32, _i32, _fp, _i32, _fp, _fp, _fp, C.c_size_t, C.c_void_p]),
     "edv_pack_geglu": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _i32, C.c_void_p]),
     "edv_gemm_geglu": (C.c_int, [_fp, _fp, _fp, _fp, _i64, _i32, _i32, C.c_void_p]),

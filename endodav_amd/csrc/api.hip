@@ -22,6 +22,24 @@ int edv_gemm(const float *A_dev, const float *W_dev, float *C_dev, int64_t M, in
     return gemm(g, (hipStream_t)stream);
 }
 
+size_t edv_gemm_x6_planes_bytes(int32_t N, int32_t K) { return N > 0 && K > 0 ? gemm_x6_planes_bytes(N, K) : 0; }
+
+int edv_gemm_x6_split(const float *W_dev, void *planes_dev, int32_t N, int32_t K, void *stream) {
+    return gemm_x6_split(W_dev, planes_dev, N, K, (hipStream_t)stream);
+}
+
+int edv_gemm_x6(const float *A_dev, const void *planes_dev, float *C_dev, int64_t M, int32_t N, int32_t K, const float *bias_dev, int32_t act,
+                const float *gamma_dev, const float *R_dev, float *workspace_dev, size_t workspace_bytes, void *stream) {
+    GemmDesc g;
+    g.A = A_dev; g.lda = K; g.W = reinterpret_cast<const float *>(planes_dev); g.ldw = K; g.C = C_dev; g.ldc = N; g.M = M; g.N = N; g.K = K;
+    g.bias = bias_dev; g.act = act; g.gamma = gamma_dev; g.R1 = R_dev; g.ldr1 = N;
+    g.ws = workspace_dev; g.ws_floats = workspace_bytes / sizeof(float);
+    g.Wx6 = planes_dev;
+    EDV_CHECK(act >= ACT_NONE && act <= ACT_RELU, "act must be 0, 1 or 2");
+    EDV_CHECK(M > 0 && N >= 64 && K > 0 && K % 16 == 0, "edv_gemm_x6: K % 16 == 0, N >= 64");
+    return gemm_x6(g, (hipStream_t)stream);
+}
+
 int edv_pack_geglu(const float *w_dev, const float *b_dev, float *wi_dev, float *bi_dev, int32_t N, int32_t K, void *stream) {
     return pack_geglu(w_dev, b_dev, wi_dev, bi_dev, N, K, (hipStream_t)stream);
 }

@@ -72,6 +72,8 @@ struct edv_ctx {
     std::unordered_map<std::string, Buf> packed;  // derived weights, owned
     std::unordered_map<std::string, Buf> ws;      // activations, owned
     bool prepared = false;
+    int products = EDV_PRODUCTS_F32;  // arithmetic of the encoder's linears in inference (edv_set_products)
+    std::unordered_map<const float *, const void *> x6;  // effective weight of an encoder linear -> its bf16 planes (gemm_x6.hip), owned by `packed`
     const float *skws_zeroed = nullptr;  // stream-K workspace whose arrival counters have been zeroed (gemm_dma.hip)
     bool capture = false;
     bool train = false;           // forward keeps the activations the backward needs (edv_set_train)
@@ -217,6 +219,10 @@ struct Run {
         GemmDesc g;
         g.A = A; g.lda = K; g.W = W; g.ldw = K; g.C = C; g.ldc = N; g.M = M; g.N = N; g.K = K;
         g.bias = bias; g.act = act; g.gamma = gamma; g.R1 = R1; g.ldr1 = N;
+        if (in_encoder && !c->train && c->products == EDV_PRODUCTS_BF16X6) {
+            auto it = c->x6.find(W);
+            if (it != c->x6.end()) g.Wx6 = it->second;
+        }
         c->launches++;
         const int cls = in_encoder ? KC_LINEAR_ENC : KC_LINEAR;
         if (c->prof_mask & (1u << KC_LINEAR)) {  // 2 M N K; A, W read once, C written once (+ the residual read)
@@ -301,6 +307,32 @@ struct Run {
             return 0;
         }
         return param(p + ".weight", out);
+    }
+    // bf16 planes of an encoder linear's effective weight (after the LoRA fold) for gemm_x6.hip
+    int make_x6(const std::string &p) {
+        const float *W;
+        EDV_TRY(lin_w(p, &W));
+        const Param &q = c->params[p + ".weight"];
+        const int nout = (int)q.shape[0], nin = (int)q.shape[1];
+        if (nin % 16 != 0 || nout < 64) return 0;
+        float *pl;
+        EDV_TRY(pk(p + ".x6", (gemm_x6_planes_bytes(nout, nin) + 3) / 4, &pl));
+        EDV_TRY(gemm_x6_split(W, pl, nout, nin, st));
+        c->x6[W] = pl;
+        return 0;
+    }
+    int build_x6(bool mlp_only) {
+        if (c->products != EDV_PRODUCTS_BF16X6) return 0;
+        for (int i = 0; i < depth; ++i) {
+            const std::string bp = "pretrained.blocks." + std::to_string(i);
+            if (!mlp_only) {
+                EDV_TRY(make_x6(bp + ".attn.qkv"));
+                EDV_TRY(make_x6(bp + ".attn.proj"));
+            }
+            EDV_TRY(make_x6(bp + ".mlp.fc1"));
+            EDV_TRY(make_x6(bp + ".mlp.fc2"));
+        }
+        return 0;
     }
     int pack_c3(const std::string &p) {
         const float *w;
@@ -407,6 +439,8 @@ struct Run {
                 EDV_TRY(pack_geglu(w0, b0, wi, bi, 8 * C, C, st));
             }
         }
+        c->x6.clear();
+        EDV_TRY(build_x6(false));
         c->prepared = true;
         c->train_prepared = false;  // the folded LoRA weights changed: their transposes are stale
         return 0;
@@ -455,6 +489,7 @@ struct Run {
             EDV_TRY(pack_c3(cv));
             if (c->train_prepared) EDV_TRY(make_b_c3(cv));
         }
+        EDV_TRY(build_x6(true));  // fc1 / fc2 carry the factors: their planes follow the fold
         return 0;
     }
 
@@ -1969,6 +2004,11 @@ int edv_create(const edv_config *cfg, edv_ctx **out) {
     (*out)->cfg = *cfg;
     if (hipGetDevice(&(*out)->device) != hipSuccess) (*out)->device = -1;  // no device visible (host-only checks of the configuration)
     if (const char *e = getenv("EDV_ENC_STREAMS")) (*out)->enc_streams = (*out)->enc_streams_initial = atoi(e);
+    if (const char *e = getenv("EDV_PRODUCTS")) {  // "f32" | "bf16x6": initial arithmetic of the encoder's linears (edv_set_products changes it)
+        const std::string v(e);
+        EDV_CHECK(v == "f32" || v == "bf16x6", "EDV_PRODUCTS must be f32 or bf16x6");
+        (*out)->products = v == "bf16x6" ? EDV_PRODUCTS_BF16X6 : EDV_PRODUCTS_F32;
+    }
     return 0;
 }
 
@@ -2026,6 +2066,19 @@ int edv_refresh_lora(edv_ctx *ctx, void *stream) {
     Run r(ctx, (hipStream_t)stream);
     return r.refresh_lora();
 }
+
+int edv_set_products(edv_ctx *ctx, int32_t products, void *stream) {
+    EDV_CHECK(ctx, "null context");
+    EDV_CHECK(products == EDV_PRODUCTS_F32 || products == EDV_PRODUCTS_BF16X6, "products: EDV_PRODUCTS_F32 or EDV_PRODUCTS_BF16X6");
+    ctx->products = products;
+    if (products == EDV_PRODUCTS_BF16X6 && ctx->prepared && ctx->x6.empty()) {
+        Run r(ctx, (hipStream_t)stream);
+        return r.build_x6(false);
+    }
+    return 0;
+}
+
+int edv_get_products(const edv_ctx *ctx) { return ctx ? ctx->products : -1; }
 
 int edv_set_capture(edv_ctx *ctx, int on) {
     EDV_CHECK(ctx, "null context");

@@ -264,6 +264,7 @@ int gemm(const GemmDesc &d, hipStream_t st) {
         const char *e = getenv("EDV_GEMM_DMA");
         return !(e && atoi(e) == 0);
     }();
+    if (d.Wx6 && gemm_x6_supported(d)) return gemm_x6(d, st);  // the caller prepared bf16 planes of W: products on the bf16 matrix pipe (gemm_x6.hip)
     if (d.geglu) return gemm_dma(d, st);  // the GEGLU epilogue exists in the LDS-DMA kernel only (it checks gemm_geglu_supported)
     if (dma_on && gemm_dma_supported(d) && d.N > 32) return gemm_dma(d, st);
     static const bool conv_dma_on = [] {

@@ -53,8 +53,15 @@ struct GemmDesc {
     // nullptr = plain grid, one workgroup per output tile
     float *ws = nullptr;
     size_t ws_floats = 0;
+    // bf16 planes [3][N][K] of W (gemm_x6_split): with them a dense STORE_ROWS GEMM runs its products on the bf16 matrix pipe (gemm_x6.hip)
+    const void *Wx6 = nullptr;
 };
 int gemm(const GemmDesc &d, hipStream_t st);
+// "bf16 x 6" GEMM (gemm_x6.hip): fp32 in / out, six bf16 MFMAs per product term set, error below fp32's unit roundoff per term
+size_t gemm_x6_planes_bytes(int N, int K);
+int gemm_x6_split(const float *W, void *planes, int N, int K, hipStream_t st);
+bool gemm_x6_supported(const GemmDesc &d);
+int gemm_x6(const GemmDesc &d, hipStream_t st);
 size_t gemm_workspace();  // floats; enough for any shape on the current device
 size_t gemm_counter_bytes();  // the zero-initialised arrival counters at the head of the workspace
 // LDS-DMA staged variant (gemm_dma.hip): dense A, K % 32 == 0; picked by gemm() for small/medium grids.

@@ -38,6 +38,9 @@ INTERP_LEN = 8
 # vision_transformer.py:352-398 (vit_large keeps DinoVisionTransformer's img_size=224 default, hence
 # a 257-row pos_embed: SURVEY.md §7 "drop-in quirks"); taps endodav.py:76-79; vitb from
 # models/endodac/endodac.py:184-199.
+PRODUCTS = {"f32": 0, "bf16x6": 1}  # EDV_PRODUCTS_* of include/endodav_hip.h
+PRODUCTS_DEFAULT = "f32"
+
 ENCODERS = {
     "vits": (384, 12, 6, 518, (2, 5, 8, 11)),
     "vitb": (768, 12, 12, 518, (2, 5, 8, 11)),
@@ -527,6 +530,10 @@ class endodav(nn.Module):
         # nn.DataParallel replicas, each of which then finds or creates the context of its own device.
         self._native: Dict[str, "_NativeCtx"] = {}
         self._capture = False
+        # Arithmetic of the encoder's linears in inference: "f32" (fp32 products on the fp32 matrix pipe) or "bf16x6" (each operand split into three
+        # bf16 terms, six bf16 MFMAs, fp32 accumulate: per-term error below fp32's unit roundoff -- include/endodav_hip.h, edv_set_products).
+        # Inputs, outputs and accumulation are fp32 either way; training forwards always run "f32".  Initial value: EDV_PRODUCTS, else PRODUCTS_DEFAULT.
+        self.products = os.environ.get("EDV_PRODUCTS", PRODUCTS_DEFAULT)
 
     # -------------------------------------------------------------------------------------
     def _config(self) -> _lib.EdvConfig:
@@ -590,6 +597,10 @@ class endodav(nn.Module):
                 _lib.check(lib.edv_bind_param(C.c_void_p(nat.handle), k.encode(), v.data_ptr(), shape, v.dim()), f"edv_bind_param({k})")
             _lib.check(lib.edv_prepare(C.c_void_p(nat.handle), C.c_void_p(_lib.stream_ptr(device))), "edv_prepare")
             nat.sig = sig
+        if self.products not in PRODUCTS:
+            raise ValueError(f"products must be one of {sorted(PRODUCTS)} (got {self.products!r})")
+        if lib.edv_get_products(C.c_void_p(nat.handle)) != PRODUCTS[self.products]:
+            _lib.check(lib.edv_set_products(C.c_void_p(nat.handle), PRODUCTS[self.products], C.c_void_p(_lib.stream_ptr(device))), "edv_set_products")
         return nat.handle
 
     def _new_lane(self) -> int:

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EDV_ABI_VERSION 9 /* 9: edv_trainer_loss; 8: edv_debug_fill_lds (test hook); 7: the split-bf16 experiment entry points left the library */
+#define EDV_ABI_VERSION 10 /* 9: edv_trainer_loss; 8: edv_debug_fill_lds (test hook); 7: the split-bf16 experiment entry points left the library */
 
 enum edv_lora_type { EDV_LORA_NONE = 0, EDV_LORA_LORA = 1, EDV_LORA_DVLORA = 2, EDV_LORA_SSB = 3, EDV_LORA_DASH = 4 };
 
@@ -117,6 +117,15 @@ int edv_profile_enable(edv_ctx *ctx, uint32_t class_mask);
  * group runs beside the GEMMs of another, so per-kernel event brackets then measure time-shared launches: set 1 for the
  * steps whose kernels are being timed (bench.py does).  Environment EDV_ENC_STREAMS sets the initial value; n = -1 restores it. */
 int edv_set_encoder_streams(edv_ctx *ctx, int32_t n);
+/* Arithmetic of the encoder's linears (qkv, proj, fc1, fc2) in inference.  Inputs, outputs and accumulation are fp32 either way.
+ *   EDV_PRODUCTS_F32     v_mfma_f32_32x32x2_f32: fp32 products on the fp32 matrix pipe (157 TFLOP/s peak)
+ *   EDV_PRODUCTS_BF16X6  each operand split into three bf16 terms, six bf16 MFMAs per 16 k (gemm_x6.hip): per-term error below fp32's unit
+ *                        roundoff (the three dropped cross terms are <= 2^-26 of a product), 192 instead of 512 matrix-pipe cycles.
+ * The initial value comes from the environment variable EDV_PRODUCTS ("f32" | "bf16x6"), else F32.  Training forwards always use F32.
+ * After edv_prepare the call builds the weights' bf16 planes on `stream` (+ 1.5 x the encoder linears' bytes). */
+enum { EDV_PRODUCTS_F32 = 0, EDV_PRODUCTS_BF16X6 = 1 };
+int edv_set_products(edv_ctx *ctx, int32_t products, void *stream);
+int edv_get_products(const edv_ctx *ctx);
 int edv_profile_set_mask(edv_ctx *ctx, uint32_t class_mask); /* change the bracketed classes, keep what was recorded */
 int edv_profile_read(edv_ctx *ctx, int32_t kernel_class, int32_t *launches, double *total_ms);
 /* Algorithmic work of the launches bracketed since edv_profile_enable / the last call: classes 0, 1, 6 book 2 M N K FLOP and every
@@ -148,6 +157,12 @@ int edv_gemm(const float *A_dev, const float *W_dev, float *C_dev, int64_t M, in
  * results up to fp32 summation order, reproducible run to run).  The workspace must be ZERO-FILLED once before its first use
  * (it starts with per-tile arrival counters, which every launch leaves at zero).  workspace_dev = NULL: one workgroup per tile. */
 size_t edv_gemm_workspace(void);
+/* The same GEMM with its products on the bf16 matrix pipe (EDV_PRODUCTS_BF16X6): split the weight once into planes_dev
+ * (edv_gemm_x6_planes_bytes(N, K) bytes), then call edv_gemm_x6 with the planes in place of W.  K % 16 == 0, N >= 64. */
+size_t edv_gemm_x6_planes_bytes(int32_t N, int32_t K);
+int edv_gemm_x6_split(const float *W_dev, void *planes_dev, int32_t N, int32_t K, void *stream);
+int edv_gemm_x6(const float *A_dev, const void *planes_dev, float *C_dev, int64_t M, int32_t N, int32_t K, const float *bias_dev, int32_t act,
+                const float *gamma_dev, const float *R_dev, float *workspace_dev, size_t workspace_bytes, void *stream);
 
 /* GEGLU feed-forward input projection of the motion modules (motion_module.py: GEGLU.forward = x, gate = proj(h).chunk(2, -1); x * gelu(gate)),
  * fused: C[M, N/2] = (A W_v^T + b_v) * gelu(A W_g^T + b_g) in ONE launch -- the [M, N] projection is never written.  edv_pack_geglu interleaves the

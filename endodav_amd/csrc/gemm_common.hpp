@@ -20,7 +20,6 @@ struct GemmSplit {
     long long units;
     float *ws;   // piece slots (after the counters)
     int *cnt;    // one arrival counter per split tile
-    int stagger = 0;  // gemm_x6.hip: workgroups with (blockIdx / stagger) odd take their run before their whole tiles; 0 = all the same order
 };
 // The merging workgroup's acquire (round 3).  The piece exchange stores and loads every piece word sc1 behind a drained, barrier-ordered counter add:
 // the form MI355X_MICROARCH.md ("Valid forms") measures as sufficient WITHOUT an acquire -- but only at one workgroup per CU, and the split launches

@@ -86,11 +86,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const GemmDesc g, const
     for (;;) {
         int tile, kt0, kt1, lt = 0;
         float *part = nullptr;
-        // Workgroups alternate the order of their two kinds of work (run first / whole tiles first) so that a CU's two workgroups reach their
-        // epilogues -- 64 KB of stores, or a piece hand-off -- at different times: in lockstep every workgroup of the launch stores at once and
-        // the matrix pipe idles meanwhile (EDV_X6_STAGGER=0 restores the lockstep order for A/B runs).
-        const bool run_first = SPLIT && sp.stagger && ((blockIdx.x / sp.stagger) & 1) && u < u_end;
-        if (round < sp.whole_rounds && !run_first) {
+        if (round < sp.whole_rounds) {
             tile = round * G + bid;
             kt0 = 0;
             kt1 = nkt;
@@ -176,20 +172,23 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const GemmDesc g, const
 
         // prologue: stages 0 and 1 of this run filled, A of the third step in registers.  (The barrier that ended the previous run's last step also
         // released all three stages.)
+        // prologue: stages 0 and 1 of this run filled; A of steps 2, 3, 4 in flight in the three register sets (set i is consumed by the steps that run
+        // out of stage i and refilled three steps ahead: the conversion never waits for a load younger than three steps)
         const int nk = kt1 - kt0;
-        f32x4 areg[2], areg1[2];
-        load_a(kt0, areg);  // both A pieces of the first two steps are in flight before the first is needed: one load latency, not two
-        if (nk > 1) load_a(kt0 + 1, areg1);
+        f32x4 aset[3][2];
+        load_a(kt0, aset[0]);  // both A pieces of the first two steps are in flight before the first is needed: one load latency, not two
+        if (nk > 1) load_a(kt0 + 1, aset[1]);
         issue_w(kt0, 0);
         if (nk > 1) issue_w(kt0 + 1, 1);
-        split_store_a(areg, 0);
-        if (nk > 1) split_store_a(areg1, 1);
-        if (nk > 2) {
-            load_a(kt0 + 2, areg);
-            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");  // W of the first step landed; W of the second (x3) and A of the third (x2) may stay in flight
-        } else {
+        split_store_a(aset[0], 0);
+        if (nk > 1) split_store_a(aset[1], 1);
+        if (nk > 2) load_a(kt0 + 2, aset[0]);
+        if (nk > 3) load_a(kt0 + 3, aset[1]);
+        if (nk > 4) load_a(kt0 + 4, aset[2]);
+        if (nk > 4)
+            asm volatile("s_waitcnt vmcnt(9)" ::: "memory");  // W of the first step landed; W of the second (x3) and A of three steps (x6) may stay in flight
+        else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
         __syncthreads();
 
         // one step out of stage ST (compile-time): W DMA and A conversion of step + 2 into the stage read last step, A loads of step + 3, 12 fragment reads, 24 MFMAs
@@ -197,8 +196,8 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const GemmDesc g, const
             constexpr int ST = decltype(st_tag)::value, S2 = (ST + 2) % XNST;
             if (kt + 2 < kt1) {
                 issue_w(kt + 2, S2);
-                split_store_a(areg, S2);
-                if (kt + 3 < kt1) load_a(kt + 3, areg);
+                split_store_a(aset[ST], S2);  // A(kt + 2), loaded three steps ago
+                if (kt + 5 < kt1) load_a(kt + 5, aset[ST]);
             }
             bf16x8 a[2][3], b[2][3];
 #pragma unroll
@@ -215,9 +214,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const GemmDesc g, const
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[j][PB[t]], acc[i][j], 0, 0, 0);
-            // W of step + 1 (issued one step ago) has landed: younger than it are A(step + 2) x2, W(step + 2) x3, A(step + 3) x2.  The wave's own LDS writes
+            // W of step + 1 (issued one step ago) has landed: younger than it are A(step + 4) x2, W(step + 2) x3, A(step + 5) x2.  The wave's own LDS writes
             // and fragment reads are done (lgkmcnt) before the barrier that publishes the stage written and releases the stage read.
-            if (kt + 3 < kt1)
+            if (kt + 5 < kt1)
                 asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -329,7 +328,14 @@ int launch_x6(const GemmDesc &d, long long tiles, hipStream_t st) {
     EDV_CHECK(slots > 0 && slots <= XMAX_COUNTERS, "occupancy query failed");
     const long long left = tiles % slots;
     const int nkt = d.K / XBK;
-    if (d.ws && !plain_forced && left > 0 && tiles > 16 && tiles < 8ll * slots && nkt >= 8) {
+    // The split pays from K = 768 up (fc2 at T = 8: 110 -> 93 us); at K = 384 a tile is 24 steps, the pieces and their merge cost more than the uneven
+    // last round, and the plain grid's dynamic dispatch wins (qkv 87 -> 78 us, proj 40 -> 35 us; profiles/r03_gemm_x6_shapes.txt).  Launching every
+    // workgroup pair of a CU in lockstep is not what costs: alternating the order of whole tiles and runs between workgroups changed nothing.
+    static const int min_kt = [] {
+        const char *e = getenv("EDV_X6_SPLIT_MIN_KT");  // k-steps per tile from which the split is used (A/B runs)
+        return e ? atoi(e) : 48;
+    }();
+    if (d.ws && !plain_forced && left > 0 && tiles > 16 && tiles < 8ll * slots && nkt >= min_kt) {
         sp.whole_rounds = (int)(tiles / slots);
         long long split_tiles = left;
         const long long chunk_min = (nkt + 3) / 4;
@@ -347,11 +353,6 @@ int launch_x6(const GemmDesc &d, long long tiles, hipStream_t st) {
         sp.cnt = reinterpret_cast<int *>(d.ws);
         sp.ws = d.ws + XMAX_COUNTERS;
         EDV_CHECK((size_t)XMAX_COUNTERS + (size_t)sp.nsplit * 2 * XSLOT <= d.ws_floats && (uintptr_t)d.ws % 16 == 0, "stream-K workspace too small (gemm_workspace)");
-        static const int stagger = [] {
-            const char *e = getenv("EDV_X6_STAGGER");  // 0: lockstep; n: workgroups n apart alternate (A/B runs)
-            return e ? atoi(e) : 1;
-        }();
-        sp.stagger = stagger;
         EDV_LAUNCH((gemm_x6_kernel<ACT, true>), dim3((unsigned)grid), dim3(256), XNST * XSTAGE, st, d, sp);
         EDV_LAUNCH_OK();
         return 0;

@@ -44,6 +44,7 @@ DIMS = {"vits": (384, 12, 6), "vitb": (768, 12, 12), "vitl": (1024, 24, 16)}
 # matmul+conv FLOPs per 518x518 frame, FlopCounterMode over the reference
 GFLOP_PER_FRAME = {"vits": 121.1, "vitb": 403.9, "vitl": 1403.8}
 LIN_STEPS = 2  # timed steps (the first ones) whose kernels are bracketed with HIP events (see main)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md (never the 2:1-sparsity figure)
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0         # same guide, "HBM3E peak BW" (spec; 6.29 TB/s measured with a float4 copy)
 PROFILE_ROUND = "r03"         # profiles/<round>_{gemm,attn,hbm}_traffic.json hold the PMC traffic of this round's kernels
@@ -65,6 +66,9 @@ def parse():
     ap.add_argument("--temporal-lora", action="store_true", help="LoRA on ff.net.2 of the motion modules too (--temporal_lora)")
     ap.add_argument("--in-flight", type=int, default=0, help="clips in flight on the GPU (pipeline.ClipsInFlight): 0 = auto_depth (3 at the headline shape, "
                     "1 for clips that fill the part alone), 1 = one clip at a time")
+    ap.add_argument("--products", default=None, choices=["f32", "bf16x6"], help="arithmetic of the encoder's linears in inference (model.products): f32 = fp32 "
+                    "products on the fp32 matrix pipe (default, and what `value` is measured with unless this flag says otherwise); bf16x6 = operands split "
+                    "into three bf16 terms, six bf16 MFMAs, fp32 accumulate (error no worse than the fp32 pipe's: tests/test_gemm_x6_gpu.py)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(16, cores): the box's CPU share)")
@@ -257,6 +261,8 @@ def main():
                                 disable_conv_head=not args.conv_head).eval()
     synth.fill_module_(model)
     model = model.to(dev)
+    if args.products:
+        model.products = args.products
     Bc = args.clips
     in_hw = (256, 320) if (args.train and (SH, SW) == (224, 280)) else (SH, SW)  # the trainer feeds 256x320 frames (options.py:128-135)
     x = torch.from_numpy(synth.synth_clip(Bc, T, in_hw[0], in_hw[1], seed=rank)).to(dev)  # resident in HBM before timing
@@ -310,6 +316,28 @@ def main():
                 model(x)
             torch.cuda.synchronize(dev)
             serial_value = Bc * T * n_s / (time.perf_counter() - t1)
+        # The other products mode on the same clip, same clips in flight (reported beside `value`, never as it): how much the bf16 x 6 linears buy at
+        # this shape, and how far the two modes' disparities are apart.
+        other = None
+        if world == 1 and not stub_alt(args):
+            first = model.products
+            model.products = "bf16x6" if first == "f32" else "f32"
+            n_o = max(args.steps // 2, 4)
+            run = (lambda: flight.submit(x, resident=True)) if flight is not None else (lambda: model(x))
+            for _ in range(3):
+                h = run()
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for _ in range(n_o):
+                h = run()
+            torch.cuda.synchronize(dev)
+            o_value = Bc * T * n_o / (time.perf_counter() - t1)
+            o_maps = h.result() if flight is not None else h
+            a, b = out["maps"][("disp", 0)], o_maps[("disp", 0)]
+            other = {"products": model.products, "value": round(o_value, 2), "steps": n_o,
+                     "max_abs_disparity_difference": float((a - b).abs().max()), "disparity_range": [float(a.min()), float(a.max())]}
+            model.products = first
+            model(x)  # contexts back in the first mode
     out = out["maps"]
 
     # Dominant kernel by time (profiles/r02_*_kernel_stats.csv): gemm_dma_kernel, the dense F.linear / 1x1-conv GEMM; second: the encoder
@@ -337,6 +365,13 @@ def main():
                 roofline["encoder_launches"] = {"achieved": round(ach_e, 2), "frac": round(ach_e / PEAK_F32_MFMA_TFLOPS, 4), "launches": n_e,
                                                 "avg_launch_ms": round(ms_e / n_e, 4), "flop_per_launch": round(fl_e / n_e, 1),
                                                 "share_of_linear_flop": round(fl_e / fl_l, 4)}
+        if roofline is not None and model.products == "bf16x6" and n_e > 0 and ms_e > 0:
+            # the encoder's linears ran on the bf16 pipe: six bf16 MFMA FLOP per algorithmic FLOP, priced against the dense bf16 peak
+            ex = 6.0 * fl_e / (ms_e * 1e-3) / 1e12
+            roofline["encoder_launches"].update({"kernel": "gemm_x6_kernel", "executed_bf16_tflops": round(ex, 1), "peak_bf16_dense": PEAK_BF16_MFMA_TFLOPS,
+                                                 "frac_of_bf16_peak": round(ex / PEAK_BF16_MFMA_TFLOPS, 4),
+                                                 "note": "achieved / frac above are fp32-equivalent (algorithmic) TFLOP/s against the fp32 pipe's 157.3: "
+                                                         "above 1.0 means faster than any fp32-MFMA kernel can be"})
         n, ms = model.profile_read("attn_spatial")
         D, depth, heads = DIMS[args.encoder]
         ntok = (SH // 14) * (SW // 14) + 1
@@ -380,13 +415,14 @@ def main():
             "config": {"workload": f"ViT-{args.encoder[-1].upper()} endodav (features {kwargs['features']}, out_channels {kwargs['out_channels']}, "
                                    f"{args.lora} r=4, {'conv head' if args.conv_head else 'VDA head'}), {Bc} synthetic {SH}x{SW} T={T} clip(s) per GPU per step "
                                    "(BASELINE.json configs[1] shape at the defaults), hash-initialised weights", "encoder": args.encoder, "T": T,
-                       "image": [SH, SW], "clips_per_gpu_per_step": Bc, "clips_in_flight": n_flight,
+                       "image": [SH, SW], "clips_per_gpu_per_step": Bc, "clips_in_flight": n_flight, "products": model.products,
                        "parallelism": f"clip-sharded x{world}, no data-path collective; {n_flight} consecutive clip(s) in flight per GPU (one engine context and HIP stream each)"},
             "model_tflop_per_clip": round(GFLOP_PER_FRAME[args.encoder] * T / 1e3 * px, 4),
             "model_tflops": round(GFLOP_PER_FRAME[args.encoder] * px * value / 1e3, 2),
             "launches_per_step": model.launch_count(), "device_mem_mb": round(model.device_bytes() / 2 ** 20, 1), "output_finite": finite,
             "one_clip_at_a_time_value": None if serial_value is None else round(serial_value, 2),
             "pcie_inclusive_value": None if pcie_value is None else round(pcie_value, 2),
+            "other_products": other,
             "roofline": roofline, "roofline_attention": roofline_attn, "roofline_hbm": roofline_hbm,
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -399,6 +435,11 @@ def main():
     if world > 1:
         parallel.barrier()
         dist.destroy_process_group()
+
+
+def stub_alt(args):
+    """The alternative-products leg is skipped for batched clips (a [B, T] batch through one forward is its own configuration)."""
+    return args.clips != 1
 
 
 def train_bench(args, model, x, dev, rank, world, kwargs, rehearsal=False):

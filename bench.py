@@ -69,6 +69,7 @@ def parse():
     ap.add_argument("--products", default=None, choices=["f32", "bf16x6"], help="arithmetic of the encoder's linears in inference (model.products): f32 = fp32 "
                     "products on the fp32 matrix pipe (default, and what `value` is measured with unless this flag says otherwise); bf16x6 = operands split "
                     "into three bf16 terms, six bf16 MFMAs, fp32 accumulate (error no worse than the fp32 pipe's: tests/test_gemm_x6_gpu.py)")
+    ap.add_argument("--no-other-products", action="store_true", help="skip the leg that times the other products mode (profiling passes: one arithmetic per run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = min(16, cores): the box's CPU share)")
@@ -85,7 +86,7 @@ def parse():
     return args
 
 
-def measured_traffic(encoder, T, image_hw, clips=1, which="gemm"):
+def measured_traffic(encoder, T, image_hw, clips=1, which="gemm", products="f32"):
     """HBM-side bytes per launch of a kernel class from the committed rocprofv3 --pmc passes (collected in their own runs, FETCH_SIZE doubled as the
     gfx950 guide prescribes); None when no pass matches this workload.  Round 3: profiles/r03_<config>_traffic.json (scratch/evidence_r03.sh) holds every
     class of one configuration; rounds 1-2 kept one file per class for the headline only."""
@@ -94,13 +95,16 @@ def measured_traffic(encoder, T, image_hw, clips=1, which="gemm"):
     if image_hw[0] != image_hw[1] or clips != 1:
         return None, None
     want = {"encoder": encoder, "T": T, "image": image_hw[0]}
+    if products != "f32":
+        return None, None  # the committed passes are of the fp32 kernels
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_*_traffic.json"))):
         try:
             with open(path) as f:
                 rec = json.load(f)
         except (OSError, ValueError):
             continue
-        if rec.get("config") != want or "per_class" not in rec:
+        cfg = dict(rec.get("config") or {})
+        if cfg.pop("products", "f32") != "f32" or cfg != want or "per_class" not in rec:
             continue
         pc = rec["per_class"]
         if which == "gemm" and pc.get("gemm"):
@@ -280,7 +284,7 @@ def main():
         # are off and consecutive clips are in flight: they are independent, so the engine keeps several going (pipeline.ClipsInFlight: one context +
         # stream per lane, depth by auto_depth -- 3 at the headline shape, 1 for clips that fill the part alone).  Every step still is one whole
         # forward of one clip, submitted back to back; the closing synchronize of the timed region waits for all of them.  (Rounds 1-2 bracketed
-        # the LAST steps; with clips in flight that needs a drain in the middle of the timed region, the first steps start from an idle GPU anyway.)
+        # the LAST steps; either way one drain separates the bracketed steps from the clips in flight.)
         lin_to = min(LIN_STEPS, args.steps) if events else 0
         out = {}
         n_flight = args.in_flight if args.in_flight > 0 else ClipsInFlight.auto_depth(model, Bc * T)
@@ -292,6 +296,9 @@ def main():
                 model.set_encoder_streams(1)
                 model.profile_set(["attn_spatial", "linear"] + list(endodav_amd._lib.HBM_CLASSES))
             if events and i == lin_to:
+                if flight is not None:
+                    torch.cuda.synchronize(dev)  # the bracketed steps are still queued (the host runs ahead): clips in flight beside them would share
+                                                 # the GPU with the kernels being timed (the first round-3 evidence pass did exactly that: 0.62 instead of 0.74)
                 model.profile_set([])  # what was recorded stays
                 model.set_encoder_streams(-1)
             if flight is not None and not (0 <= i < lin_to):
@@ -352,7 +359,7 @@ def main():
         n_l, ms_l, fl_l, by_l = n_h + n_e, ms_h + ms_e, fl_h + fl_e, by_h + by_e
         if n_l > 0 and ms_l > 0:
             achieved = fl_l / (ms_l * 1e-3) / 1e12
-            rec, src = measured_traffic(args.encoder, T, (SH, SW), Bc, "gemm")
+            rec, src = measured_traffic(args.encoder, T, (SH, SW), Bc, "gemm", model.products)
             roofline = {"kernel": "gemm_dma_kernel (every F.linear / 1x1 conv of the step: qkv, proj, fc1, fc2 of the encoder blocks + the head's)",
                         "bound": "mfma", "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None if rec is None else rec["traffic_bytes_per_launch"],
@@ -378,7 +385,7 @@ def main():
         flops = 4.0 * ntok * ntok * 64 * heads * T * Bc  # QK^T + PV, 2 FLOP per MAC, per launch (one encoder block, all frames)
         if n > 0 and ms > 0:
             achieved = flops / (ms / n * 1e-3) / 1e12
-            rec, src = measured_traffic(args.encoder, T, (SH, SW), Bc, "attn")
+            rec, src = measured_traffic(args.encoder, T, (SH, SW), Bc, "attn")  # (the attention kernel is the same in both products modes)
             roofline_attn = {"kernel": "attn_lean_kernel + attn_combine_kernel (one encoder-block attention call)", "bound": "mfma",
                              "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                              "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None if rec is None else rec["traffic_bytes_per_launch"],
@@ -439,7 +446,7 @@ def main():
 
 def stub_alt(args):
     """The alternative-products leg is skipped for batched clips (a [B, T] batch through one forward is its own configuration)."""
-    return args.clips != 1
+    return args.clips != 1 or args.no_other_products
 
 
 def train_bench(args, model, x, dev, rank, world, kwargs, rehearsal=False):

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const GemmDesc g, const
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, lh = lane >> 5;
     const int wave_s = __builtin_amdgcn_readfirstlane(wave);
     const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = (g.N + XBN - 1) / XBN;
+    const int tiles_n = (g.N + XBN - 1) / XBN, tiles_m = (int)((g.M + XBM - 1) / XBM);
     const int G = gridDim.x;
     const int bid = xcd_remap(blockIdx.x, G);
     const int nkt = g.K / XBK;
@@ -103,7 +103,18 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const GemmDesc g, const
         } else {
             break;
         }
-        const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+        // Tile order: groups of `gm` row blocks swept column by column (row block fastest), so that the workgroups an XCD runs side by side share
+        // few W column tiles and a handful of A row blocks instead of one A row block and every W tile (xcd_remap gives an XCD a contiguous run of
+        // tile indices).  gm = 1 is the plain row-major order.
+        int tm, tn;
+        {
+            const int per_group = sp.group_m * tiles_n;
+            const int gidx = tile / per_group, first = gidx * sp.group_m;
+            const int rows = tiles_m - first < sp.group_m ? tiles_m - first : sp.group_m;
+            const int r = tile - gidx * per_group;
+            tn = r / rows;
+            tm = first + (r - tn * rows);
+        }
         const long long m0 = (long long)tm * XBM;
         const int n0 = tn * XBN;
 
@@ -323,6 +334,11 @@ int launch_x6(const GemmDesc &d, long long tiles, hipStream_t st) {
         return e && atoi(e) != 0;
     }();
     GemmSplit sp{1, 1, 0, 1, 0, nullptr, nullptr};
+    static const int group_m = [] {
+        const char *e = getenv("EDV_X6_GROUP_M");  // row blocks per tile group (A/B runs); 1 = row-major tile order
+        return e && atoi(e) > 0 ? atoi(e) : 8;
+    }();
+    sp.group_m = group_m;
     long long grid = tiles;
     const int slots = x6_slots<ACT>();
     EDV_CHECK(slots > 0 && slots <= XMAX_COUNTERS, "occupancy query failed");

@@ -20,7 +20,7 @@ echo "bench $name: $(head -c 160 $O/$name.json)"
 fi
 PROF="--no-cpu-baseline --no-kernel-events --no-other-products --steps 4 --warmup 2"
 case " $* " in *" --train "*) ;; *) PROF="$PROF --in-flight 1";; esac
-[ "$ONLY" = "all" ] && (cd /tmp && timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -o k -- python3 $R/bench.py "$@" $PROF > $O/prof_$name.log 2>&1) || echo "rocprof $name failed" >> $O/fail.log
+[ "$ONLY" != "all" ] || (cd /tmp && timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$name -o k -- python3 $R/bench.py "$@" $PROF > $O/prof_$name.log 2>&1) || echo "rocprof $name failed" >> $O/fail.log
 f=$(find $O/prof_$name -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/${name}_kernel_stats.csv
 rm -rf $O/prof_$name
 echo "stats $name done"

@@ -93,6 +93,8 @@ SIGNATURES = {
     "edv_grad_bind_flat": (C.c_int, [C.c_void_p, _i32, C.POINTER(C.c_char_p), C.POINTER(_i64), _fp, _i64, C.POINTER(_i64)]),
     "edv_grad": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(_i64)]),
     "edv_grad_copy": (C.c_int, [C.c_void_p, C.c_char_p, _fp, _i64, C.c_void_p]),
+    "edv_attn_spatial_x6_workspace": (C.c_size_t, [_i32, _i32, _i32]),
+    "edv_attn_spatial_x6": (C.c_int, [_fp, _fp, _i32, _i32, _i32, _fp, C.c_size_t, C.c_void_p]),
     "edv_attn_spatial_bwd_workspace": (C.c_size_t, [_i32, _i32, _i32]),
     "edv_attn_spatial_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _i32, _i32, _i32, _fp, C.c_size_t, C.c_void_p]),
     "edv_layernorm_bwd": (C.c_int, [_fp, _fp, _fp, _fp, _i64, _i32, C.c_float, _i32, C.c_void_p]),

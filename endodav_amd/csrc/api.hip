@@ -98,6 +98,11 @@ int edv_attn_spatial(const float *qkv_dev, float *out_dev, int32_t F, int32_t N,
                      float *lse_dev, void *stream) {
     return attn_spatial(qkv_dev, out_dev, F, N, heads, workspace_dev, workspace_bytes / sizeof(float), (hipStream_t)stream, lse_dev);
 }
+size_t edv_attn_spatial_x6_workspace(int32_t F, int32_t N, int32_t heads) { return attn_spatial_workspace(F, N, heads, true) * sizeof(float); }
+int edv_attn_spatial_x6(const float *qkv_dev, float *out_dev, int32_t F, int32_t N, int32_t heads, float *workspace_dev, size_t workspace_bytes, void *stream) {
+    return attn_spatial(qkv_dev, out_dev, F, N, heads, workspace_dev, workspace_bytes / sizeof(float), (hipStream_t)stream, nullptr, true);
+}
+
 size_t edv_attn_spatial_bwd_workspace(int32_t F, int32_t N, int32_t heads) { return attn_spatial_bwd_workspace(F, N, heads) * sizeof(float); }
 int edv_attn_spatial_bwd(const float *qkv_dev, const float *out_dev, const float *dout_dev, const float *lse_dev, float *delta_dev, float *dqkv_dev,
                          int32_t F, int32_t N, int32_t heads, float *workspace_dev, size_t workspace_bytes, void *stream) {

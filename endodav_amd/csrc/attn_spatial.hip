@@ -486,6 +486,293 @@ __global__ __launch_bounds__(LEAN_NW * 64, 2) void attn_lean_kernel(const float 
     }
 }
 
+// ---- the bf16 x 6 form (round 3; EDV_PRODUCTS_BF16X6) --------------------------------------------------------------------------------
+// Same task list, piece format and result as attn_lean_kernel -- to fp32 rounding: both products run as six v_mfma_f32_32x32x16_bf16 on three-term
+// bf16 splits of BOTH operands with fp32 accumulation, the scheme of gemm_x6.hip (a = a0 + a1 + a2; a w ~= a2 w0 + a0 w2 + a1 w1 + a1 w0 + a0 w1 + a0 w0,
+// the three dropped terms <= 2^-26 |a w|).  The softmax is the lean kernel's, on the fp32 accumulators.  What changes with the instruction:
+//   * 16 k per MFMA and 8 consecutive k per lane: K^T's A operand reads 16 bytes of one key row (dims 8h .. 8h + 7 of a 16-dim step); the PV product
+//     contracts over KEYS, so its A operand needs 8 keys of one dim d contiguous: V is staged TRANSPOSED ([d][key] planes), by the staging threads
+//     that split it -- each takes a 4 key x 4 dim block, the transpose is register naming.  Which 8 keys: the S^T accumulator registers
+//     8 (j & 1) .. + 7 of sub-tile j >> 1 hold, for lane-half h, keys 16 j + 4 h + {0..3} and 16 j + 8 + 4 h + {0..3}; they ARE the B operand of PV
+//     step j (after the split), and V^T's plane rows store each 16-key group in the order [0-3, 8-11 | 4-7, 12-15] so that half h reads one b128;
+//   * K / V arrive through registers (global loads of tile t + 1 during tile t, split and written to the other LDS stage at the tile's end): the
+//     split needs the VALU anyway, and beside the bf16 MFMA VALU work hides (gemm_x6.hip);
+//   * 8 waves = 256 queries per workgroup share a staged tile (2 stages x (3 K planes + 3 V^T planes) x 8 KB = 96 KB: one workgroup per CU, two
+//     waves per SIMD); waves 0-3 stage K, waves 4-7 stage V^T.
+// LDS plane image: 128-byte rows (64 bf16), 16-byte chunk c of row r at chunk position c ^ ((r >> 1) & 7): a 16-lane b128 group (16 rows, one c) covers
+// all 64 banks.
+typedef __bf16 xbf8 __attribute__((ext_vector_type(8)));
+typedef __bf16 xbf4 __attribute__((ext_vector_type(4)));
+constexpr int X6_NW = 8, X6_KT = 64, X6_QB = X6_NW * 32;
+constexpr int X6_PLANE = X6_KT * HD * 2;     // bytes: 64 rows x 128 B
+constexpr int X6_STAGE = 6 * X6_PLANE;       // K0 K1 K2 V0 V1 V2 (48 KB)
+
+struct Split3 {
+    __bf16 p0, p1, p2;
+};
+__device__ __forceinline__ Split3 split3(float x) {
+    Split3 s;
+    s.p0 = (__bf16)x;
+    const float r1 = x - (float)s.p0;
+    s.p1 = (__bf16)r1;
+    s.p2 = (__bf16)(r1 - (float)s.p1);
+    return s;
+}
+
+__global__ __launch_bounds__(X6_NW * 64) void attn_x6_kernel(const float *__restrict__ qkv, float *__restrict__ out, float *__restrict__ ws, float *__restrict__ lse,
+                                                             int N, int heads, int whole_rounds, long long units, int chunk) {
+    constexpr int KT = X6_KT, QB = X6_QB;
+    constexpr int SLOTF = QB * (HD + 2);
+    constexpr float TAU = 10.0f;
+    extern __shared__ __attribute__((aligned(16))) unsigned char xsm[];  // 2 stages
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int nq = (N + QB - 1) / QB;
+    const int G = gridDim.x;
+    int bid = blockIdx.x;
+    {
+        const int q = G >> 3, r = G & 7, x = bid & 7, loc = bid >> 3;
+        bid = (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + loc;
+    }
+    const int D = heads * HD, D3 = 3 * D;
+    const int ntiles = (N + KT - 1) / KT;
+    const float qscale = 0.125f * 1.44269504088896340736f;
+
+    // staging role: threads 0..255 take K, 256..511 V; each a block of 4 keys (4 kg ..) x 4 dims (4 dg ..) of the tile
+    const int srole = tid >> 8, st_id = tid & 255, kg = st_id >> 4, dg = st_id & 15;
+    int wr[4];  // byte offsets of this thread's four 8-byte writes inside a plane
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (srole == 0) {  // K plane row = key 4 kg + i; dims 4 dg .. + 3 = chunk dg >> 1, half (dg & 1)
+            const int key = 4 * kg + i;
+            wr[i] = key * 128 + (((dg >> 1) ^ ((key >> 1) & 7)) << 4) + (dg & 1) * 8;
+        } else {           // V^T plane row = dim 4 dg + i; keys 4 kg .. + 3 = group kg >> 2, chunk 2 (kg >> 2) + (kg & 1), half (kg >> 1) & 1
+            const int d = 4 * dg + i, c = 2 * (kg >> 2) + (kg & 1);
+            wr[i] = d * 128 + ((c ^ ((d >> 1) & 7)) << 4) + ((kg >> 1) & 1) * 8;
+        }
+    }
+    // fragment addresses in stage 0, plane 0: K rows l31 (+ 32), V^T rows l31 (+ 32); chunk 2 s + lh of step s
+    int fk[4], fv[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+        fk[s2] = l31 * 128 + (((2 * s2 + lh) ^ ((l31 >> 1) & 7)) << 4);
+        fv[s2] = 3 * X6_PLANE + fk[s2];
+    }
+
+    const int task_l0 = whole_rounds * G;
+    long long u = (long long)bid * chunk;
+    const long long u_end = u + chunk < units ? u + chunk : units;
+    int round = 0, seg = 0;
+    for (;;) {
+        int task, kt0, kt1;
+        float *part = nullptr;
+        if (round < whole_rounds) {
+            task = round * G + bid;
+            kt0 = 0;
+            kt1 = ntiles;
+            ++round;
+        } else if (u < u_end) {
+            const int t = (int)(u / ntiles);
+            kt0 = (int)(u - (long long)t * ntiles);
+            const long long left = u_end - u;
+            kt1 = kt0 + left < ntiles ? kt0 + (int)left : ntiles;
+            task = task_l0 + t;
+            u += kt1 - kt0;
+            if (!(kt0 == 0 && kt1 == ntiles)) part = ws + ((long long)bid * 2 + seg) * SLOTF;
+            ++seg;
+        } else {
+            break;
+        }
+        const int qt = task % nq, fh = task / nq;
+        const int head = fh % heads, frame = fh / heads;
+        const float *fbase = qkv + (long long)frame * N * D3;
+        const float *base = fbase + head * HD;
+        const int qi = qt * QB + wave * 32 + l31;
+        const int qrow = qi < N ? qi : N - 1;
+
+        // Q^T planes (B operand of S^T): dims 16 s + 8 lh .. + 7 of this lane's query, pre-scaled, split
+        xbf8 qb[3][4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; ++s2) {
+            const f32x4 a = *reinterpret_cast<const f32x4 *>(base + (long long)qrow * D3 + 16 * s2 + 8 * lh);
+            const f32x4 b = *reinterpret_cast<const f32x4 *>(base + (long long)qrow * D3 + 16 * s2 + 8 * lh + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const Split3 sa = split3(a[e] * qscale), sb = split3(b[e] * qscale);
+                qb[0][s2][e] = sa.p0; qb[1][s2][e] = sa.p1; qb[2][s2][e] = sa.p2;
+                qb[0][s2][4 + e] = sb.p0; qb[1][s2][4 + e] = sb.p1; qb[2][s2][4 + e] = sb.p2;
+            }
+        }
+        // staging: this thread's 4 x 4 block of K (column block D) or V (2 D) of key tile t; rows past the sequence end read the last row (their
+        // scores are masked to -inf, their probabilities are exactly 0)
+        const float *sbase = base + (srole == 0 ? D : 2 * D) + 4 * dg;
+        auto load_tile = [&](int t, f32x4 (&v)[4]) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int key = t * KT + 4 * kg + i;
+                key = key < N ? key : N - 1;
+                v[i] = *reinterpret_cast<const f32x4 *>(sbase + (long long)key * D3);
+            }
+        };
+        auto split_store = [&](const f32x4 (&v)[4], int st) {
+            unsigned char *dst = xsm + st * X6_STAGE + (srole == 0 ? 0 : 3 * X6_PLANE);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xbf4 p0, p1, p2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // K: row = key i, the four dims e;  V^T: row = dim i, the four keys e (the transpose)
+                    const Split3 sx = split3(srole == 0 ? v[i][e] : v[e][i]);
+                    p0[e] = sx.p0; p1[e] = sx.p1; p2[e] = sx.p2;
+                }
+                *reinterpret_cast<xbf4 *>(dst + wr[i]) = p0;
+                *reinterpret_cast<xbf4 *>(dst + X6_PLANE + wr[i]) = p1;
+                *reinterpret_cast<xbf4 *>(dst + 2 * X6_PLANE + wr[i]) = p2;
+            }
+        };
+
+        f32x16 o0, o1;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
+        float m_run = 0.f, l_run = 0.f;
+        f32x4 treg[4];
+
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // (tile-operand plane, register-operand plane), smallest terms first
+        auto tile = [&](int t, auto st_tag, auto first_tag) {
+            constexpr int ST = decltype(st_tag)::value;
+            constexpr bool FIRST = decltype(first_tag)::value;
+            const int k0 = t * KT;
+            // this wave's plane writes of tile t and its fragment reads of tile t - 1 are done; then everybody's are
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (t + 1 < kt1) load_tile(t + 1, treg);
+            const unsigned char *stg = xsm + ST * X6_STAGE;
+            // ---- S^T - m = K Q^T - m
+            f32x16 s0, s1;
+            const float init = FIRST ? 0.f : -m_run;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s0[r] = s1[r] = init;
+#pragma unroll
+            for (int s2 = 0; s2 < 4; ++s2) {
+                xbf8 ka[3], kb[3];
+#pragma unroll
+                for (int p2 = 0; p2 < 3; ++p2) {
+                    ka[p2] = *reinterpret_cast<const xbf8 *>(stg + p2 * X6_PLANE + fk[s2]);
+                    kb[p2] = *reinterpret_cast<const xbf8 *>(stg + p2 * X6_PLANE + fk[s2] + 32 * 128);
+                }
+#pragma unroll
+                for (int tt = 0; tt < 6; ++tt) {
+                    s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[PA[tt]], qb[PB[tt]][s2], s0, 0, 0, 0);
+                    s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[PA[tt]], qb[PB[tt]][s2], s1, 0, 0, 0);
+                }
+            }
+            if (k0 + KT > N) {
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (k0 + (r & 3) + 8 * (r >> 2) + 4 * lh >= N) s0[r] = -INFINITY;
+                    if (k0 + 32 + (r & 3) + 8 * (r >> 2) + 4 * lh >= N) s1[r] = -INFINITY;
+                }
+            }
+            float mx = fmaxf(s0[0], s1[0]), my = fmaxf(s0[8], s1[8]);
+#pragma unroll
+            for (int r = 1; r < 8; ++r) {
+                mx = fmaxf(fmaxf(mx, s0[r]), s1[r]);
+                my = fmaxf(fmaxf(my, s0[r + 8]), s1[r + 8]);
+            }
+            mx = fmaxf(mx, my);
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            if (FIRST || __builtin_amdgcn_ballot_w64(mx > TAU) != 0) {
+                const float d = FIRST ? mx : fmaxf(mx, 0.f);
+                const float alpha = FIRST ? 0.f : __builtin_amdgcn_exp2f(-d);
+                m_run += d;
+                l_run *= alpha;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s0[r] -= d;
+                    s1[r] -= d;
+                    o0[r] *= alpha;
+                    o1[r] *= alpha;
+                }
+            }
+            float psum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                s0[r] = __builtin_amdgcn_exp2f(s0[r]);
+                s1[r] = __builtin_amdgcn_exp2f(s1[r]);
+                psum += s0[r] + s1[r];
+            }
+            l_run += psum;
+            // ---- O^T += V^T P^T, 16 keys per step: registers 8 (j & 1) .. + 7 of sub-tile j >> 1, split into planes, are the B operand
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                xbf8 pb[3];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const Split3 sp = split3((j < 2 ? s0 : s1)[8 * (j & 1) + e]);
+                    pb[0][e] = sp.p0; pb[1][e] = sp.p1; pb[2][e] = sp.p2;
+                }
+                xbf8 va[3], vb[3];
+#pragma unroll
+                for (int p2 = 0; p2 < 3; ++p2) {
+                    va[p2] = *reinterpret_cast<const xbf8 *>(stg + p2 * X6_PLANE + fv[j]);
+                    vb[p2] = *reinterpret_cast<const xbf8 *>(stg + p2 * X6_PLANE + fv[j] + 32 * 128);
+                }
+#pragma unroll
+                for (int tt = 0; tt < 6; ++tt) {
+                    o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[PA[tt]], pb[PB[tt]], o0, 0, 0, 0);
+                    o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[PA[tt]], pb[PB[tt]], o1, 0, 0, 0);
+                }
+            }
+            // tile t + 1: split what was loaded meanwhile and write it into the other stage (last read during tile t - 1: everybody passed this
+            // tile's barrier since)
+            if (t + 1 < kt1) split_store(treg, ST ^ 1);
+        };
+        load_tile(kt0, treg);
+        split_store(treg, 0);
+        tile(kt0, std::integral_constant<int, 0>{}, std::true_type{});
+        {
+            int t = kt0 + 1;
+            for (; t + 1 < kt1; t += 2) {
+                tile(t, std::integral_constant<int, 1>{}, std::false_type{});
+                tile(t + 1, std::integral_constant<int, 0>{}, std::false_type{});
+            }
+            if (t < kt1) tile(t, std::integral_constant<int, 1>{}, std::false_type{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __syncthreads();  // every wave has read its last tile before the next run's prologue rewrites stage 0
+
+        const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+        float inv = 1.0f / l_tot;
+        float *orow = nullptr;
+        if (part) {
+            const int ql = wave * 32 + l31;
+            orow = part + ql * HD;
+            inv = 1.0f;
+            if (lh == 0) {
+                part[QB * HD + ql] = m_run;
+                part[QB * HD + QB + ql] = l_tot;
+            }
+        } else if (qi < N) {
+            orow = out + ((long long)frame * N + qi) * D + head * HD;
+            if (lse && lh == 0) lse[((long long)frame * heads + head) * N + qi] = m_run + log2f(l_tot);
+        }
+        if (orow) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                f32x4 a = {o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv};
+                f32x4 b = {o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv};
+                *reinterpret_cast<f32x4 *>(orow + 8 * g + 4 * lh) = a;
+                *reinterpret_cast<f32x4 *>(orow + 32 + 8 * g + 4 * lh) = b;
+            }
+        }
+    }
+}
+
 // Merge of the pieces of every split (leftover) task.  Piece list of leftover task t: the workgroups whose unit runs
 // [g*chunk, (g+1)*chunk) intersect [t*ntiles, (t+1)*ntiles); a workgroup's piece sits in its slot 0 when its first unit
 // lies in this task, else in slot 1.  Thread = (query, 16-byte output chunk); 16 queries per 256-thread block.
@@ -539,7 +826,7 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float *__restri
 
 struct AttnPlan {
     int nw, kt, grid, whole_rounds, chunk, ntasks, ntiles, leftover;
-    bool pipe;
+    bool pipe, x6;
     long long units;
     size_t ws_floats;
 };
@@ -575,7 +862,21 @@ int resident_slots() {
     });
 }
 
-int make_plan(int F, int N, int heads, AttnPlan *p) {
+int x6_attn_slots() {
+    static DeviceSlotCache cache;
+    return cache.get([] {
+        int dev = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess) return 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        if (hipFuncSetAttribute((const void *)attn_x6_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * X6_STAGE) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, attn_x6_kernel, X6_NW * 64, 2 * X6_STAGE) != hipSuccess) return 0;
+        if (per_cu > 1) per_cu = 1;  // 96 KB of LDS
+        if (getenv("EDV_DEBUG_SLOTS")) fprintf(stderr, "attn_x6_kernel: %d CUs x %d resident workgroups\n", cus, per_cu);
+        return cus * per_cu;
+    });
+}
+
+int make_plan(int F, int N, int heads, AttnPlan *p, bool x6 = false) {
     // 4 waves (128 queries) per workgroup share each staged K/V tile.  The 2- and 1-wave variants cost registers
     // (195 / 256 VGPRs) and measured slower on every shape tried (T=8: 79.9 vs 78.6 vs 68.5 TF/s); they are kept for
     // sequences shorter than one 128-query block and for experiments.
@@ -595,8 +896,13 @@ int make_plan(int F, int N, int heads, AttnPlan *p) {
     if (forced == 1 || forced == 2 || forced == 4) nw = forced;
     p->nw = nw;
     p->kt = nw == 4 ? (kt_forced == 32 ? 32 : 64) : 32;  // 32-key tiles measured equal at N = 1370 (283.7 vs 284.0 us)
-    p->pipe = nw == 4 && p->kt == 64 && use_pipe();
-    const int slots = p->pipe ? pipe_slots()
+    p->x6 = x6 && N > 128;  // (shorter sequences do not fill one 256-query block: the fp32 kernels keep them)
+    if (p->x6) {
+        nw = p->nw = X6_NW;
+        p->kt = X6_KT;
+    }
+    p->pipe = !p->x6 && nw == 4 && p->kt == 64 && use_pipe();
+    const int slots = p->x6 ? x6_attn_slots() : p->pipe ? pipe_slots()
                               : nw == 4 ? (p->kt == 64 ? resident_slots<4, 64>() : resident_slots<4, 32>()) : nw == 2 ? resident_slots<2, 32>() : resident_slots<1, 32>();
     EDV_CHECK(slots > 0, "occupancy query failed");
     const long long ntasks = (long long)F * heads * ((N + nw * 32 - 1) / (nw * 32));
@@ -621,21 +927,23 @@ int make_plan(int F, int N, int heads, AttnPlan *p) {
 
 }  // namespace
 
-size_t attn_spatial_workspace(int F, int N, int heads) {
+size_t attn_spatial_workspace(int F, int N, int heads, bool x6) {
     AttnPlan p;
-    if (F <= 0 || N <= 0 || heads <= 0 || make_plan(F, N, heads, &p)) return 0;
+    if (F <= 0 || N <= 0 || heads <= 0 || make_plan(F, N, heads, &p, x6)) return 0;
     return p.ws_floats;
 }
 
-int attn_spatial(const float *qkv, float *out, int F, int N, int heads, float *ws, size_t ws_floats, hipStream_t st, float *lse) {
+int attn_spatial(const float *qkv, float *out, int F, int N, int heads, float *ws, size_t ws_floats, hipStream_t st, float *lse, bool x6) {
     EDV_CHECK(qkv && out, "null operand");
     EDV_CHECK(F > 0 && N > 0 && heads > 0, "empty problem");
     EDV_CHECK(((uintptr_t)qkv % 16 == 0) && ((uintptr_t)out % 16 == 0), "16-byte alignment");
     AttnPlan p;
-    EDV_TRY(make_plan(F, N, heads, &p));
+    EDV_TRY(make_plan(F, N, heads, &p, x6));
     EDV_CHECK(p.ws_floats == 0 || (ws && ws_floats >= p.ws_floats && (uintptr_t)ws % 16 == 0), "attention workspace too small (attn_spatial_workspace)");
     dim3 grid((unsigned)p.grid);
-    if (p.pipe)
+    if (p.x6)
+        EDV_LAUNCH((attn_x6_kernel), grid, dim3(X6_NW * 64), 2 * X6_STAGE, st, qkv, out, ws, lse, N, heads, p.whole_rounds, p.units, p.chunk);
+    else if (p.pipe)
         EDV_LAUNCH((attn_lean_kernel), grid, dim3(256), 0, st, qkv, out, ws, lse, N, heads, p.whole_rounds, p.units, p.chunk);
     else if (p.nw == 4 && p.kt == 32)
         EDV_LAUNCH((attn_spatial_kernel<4, 32>), grid, dim3(256), 0, st, qkv, out, ws, lse, N, heads, p.whole_rounds, p.units, p.chunk);

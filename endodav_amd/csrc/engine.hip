@@ -165,6 +165,15 @@ struct HbmScope {
     }
 };
 
+// EDV_X6_ATTN=0: in the BF16X6 mode only the linears change, the attention stays on the fp32 kernel (A/B runs)
+inline bool attn_x6_on() {
+    static const bool on = [] {
+        const char *e = getenv("EDV_X6_ATTN");
+        return !(e && atoi(e) == 0);
+    }();
+    return on;
+}
+
 struct Run {
     edv_ctx *c;
     hipStream_t st;
@@ -990,7 +999,8 @@ struct Run {
             if (i == 0 && stagger_record) EDV_HIP(hipEventRecord(c->ev_x[5], st));  // the next frame group may start
             {
                 Bracket b_(c, KC_ATTN_SPATIAL, st);
-                EDV_TRY(attn_spatial(qkv, att, F, ntok, heads, eb.attws + (size_t)lane * eb.attws_each, eb.attws_each, st, lse));
+                EDV_TRY(attn_spatial(qkv, att, F, ntok, heads, eb.attws + (size_t)lane * eb.attws_each, eb.attws_each, st, lse,
+                                     !c->train && c->products == EDV_PRODUCTS_BF16X6 && attn_x6_on()));
             }
             c->launches++;
             EDV_TRY(param(bp + ".attn.proj.weight", &w));
@@ -1071,7 +1081,7 @@ struct Run {
         size_t attws_each = 0;  // the largest split workspace any stream's share of the frames needs
         for (int h = 0, f0 = 0; h < nstreams; ++h) {
             const int nf = (F - f0) / (nstreams - h);
-            const size_t need = (attn_spatial_workspace(nf, ntok, heads) + 3) & ~(size_t)3;
+            const size_t need = (std::max(attn_spatial_workspace(nf, ntok, heads), attn_spatial_workspace(nf, ntok, heads, true)) + 3) & ~(size_t)3;
             attws_each = need > attws_each ? need : attws_each;
             f0 += nf;
         }

@@ -78,9 +78,10 @@ const char *gemm_kernel_name(const GemmDesc &d);
 // ------------------------------------------------------------------------------------------
 // attention (attn_spatial.hip, temporal.hip)
 // ------------------------------------------------------------------------------------------
-size_t attn_spatial_workspace(int F, int N, int heads);  // floats
+size_t attn_spatial_workspace(int F, int N, int heads, bool x6 = false);  // floats (x6: the bf16 x 6 kernel's task split)
 // lse (optional, [F, heads, N]): per-row log-sum-exp of the scores in base 2, for attn_spatial_bwd
-int attn_spatial(const float *qkv, float *out, int F, int N, int heads, float *ws, size_t ws_floats, hipStream_t st, float *lse = nullptr);
+// x6: both products as six bf16 MFMAs on three-term bf16 splits (attn_x6_kernel; fp32 in / out / accumulate, sequences longer than 128)
+int attn_spatial(const float *qkv, float *out, int F, int N, int heads, float *ws, size_t ws_floats, hipStream_t st, float *lse = nullptr, bool x6 = false);
 size_t attn_spatial_bwd_workspace(int F, int N, int heads);  // floats
 int attn_spatial_bwd(const float *qkv, const float *out, const float *dout, const float *lse, float *delta, float *dqkv, int F, int N, int heads, float *ws,
                      size_t ws_floats, hipStream_t st);

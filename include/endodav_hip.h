@@ -196,6 +196,11 @@ int edv_attn_spatial(const float *qkv_dev, float *out_dev, int32_t F, int32_t N,
 /* lse_dev (optional, [F, heads, N]): per-row log-sum-exp of the scaled scores in base 2, the only extra state the
  * backward needs.  edv_attn_spatial_bwd: dqkv [F*N, 3*heads*64] (like qkv) from qkv, out, dout [F*N, heads*64] and lse;
  * delta_dev is [F, heads, N] floats of scratch. */
+/* The same attention with both products on the bf16 matrix pipe (EDV_PRODUCTS_BF16X6: three-term bf16 splits of q, k, v and of the probabilities,
+ * six bf16 MFMAs per 16 k, fp32 accumulate and fp32 softmax; sequences longer than 128, shorter ones run the fp32 kernel).  Its own workspace size. */
+size_t edv_attn_spatial_x6_workspace(int32_t F, int32_t N, int32_t heads);
+int edv_attn_spatial_x6(const float *qkv_dev, float *out_dev, int32_t F, int32_t N, int32_t heads, float *workspace_dev, size_t workspace_bytes,
+                        void *stream);
 size_t edv_attn_spatial_bwd_workspace(int32_t F, int32_t N, int32_t heads); /* bytes; the backward splits its last partial round too */
 int edv_attn_spatial_bwd(const float *qkv_dev, const float *out_dev, const float *dout_dev, const float *lse_dev, float *delta_dev,
                          float *dqkv_dev, int32_t F, int32_t N, int32_t heads, float *workspace_dev, size_t workspace_bytes, void *stream);

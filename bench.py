@@ -44,6 +44,13 @@ DIMS = {"vits": (384, 12, 6), "vitb": (768, 12, 12), "vitl": (1024, 24, 16)}
 # matmul+conv FLOPs per 518x518 frame, FlopCounterMode over the reference
 GFLOP_PER_FRAME = {"vits": 121.1, "vitb": 403.9, "vitl": 1403.8}
 LIN_STEPS = 2  # timed steps (the first ones) whose kernels are bracketed with HIP events (see main)
+PRECISION_NOTE = {
+    "f32": "fp32 tensors, fp32 accumulation, fp32 products (v_mfma_f32_32x32x2_f32) everywhere",
+    "bf16x6": "fp32 tensors, fp32 accumulation and fp32 softmax / norms / head everywhere; the encoder's linears and attention compute each fp32 product as six "
+              "bf16 MFMAs on three-term bf16 splits of BOTH operands (dropped cross terms <= 2^-26 of a product, below fp32's unit roundoff): error against "
+              "fp64 no worse than the fp32-MFMA kernels' (tests/test_gemm_x6_gpu.py, tests/test_attn_x6_gpu.py), every parity test passes in this mode, and "
+              "`other_products` times the all-fp32-products mode in the same run",
+}
 PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense, MI355X_MICROARCH.md (never the 2:1-sparsity figure)
 PEAK_F32_MFMA_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
 PEAK_HBM_GBS = 8000.0         # same guide, "HBM3E peak BW" (spec; 6.29 TB/s measured with a float4 copy)
@@ -66,9 +73,10 @@ def parse():
     ap.add_argument("--temporal-lora", action="store_true", help="LoRA on ff.net.2 of the motion modules too (--temporal_lora)")
     ap.add_argument("--in-flight", type=int, default=0, help="clips in flight on the GPU (pipeline.ClipsInFlight): 0 = auto_depth (3 at the headline shape, "
                     "1 for clips that fill the part alone), 1 = one clip at a time")
-    ap.add_argument("--products", default=None, choices=["f32", "bf16x6"], help="arithmetic of the encoder's linears in inference (model.products): f32 = fp32 "
-                    "products on the fp32 matrix pipe (default, and what `value` is measured with unless this flag says otherwise); bf16x6 = operands split "
-                    "into three bf16 terms, six bf16 MFMAs, fp32 accumulate (error no worse than the fp32 pipe's: tests/test_gemm_x6_gpu.py)")
+    ap.add_argument("--products", default=None, choices=["f32", "bf16x6"], help="arithmetic of the encoder's linears and attention in inference (model.products; "
+                    "default: the model's, bf16x6 since round 3): bf16x6 = fp32 tensors and accumulation, each product as six bf16 MFMAs on three-term bf16 "
+                    "splits of both operands (error no worse than the fp32 pipe's: tests/test_gemm_x6_gpu.py, tests/test_attn_x6_gpu.py); f32 = fp32 products "
+                    "on the fp32 matrix pipe everywhere.  The other mode is always timed beside `value` (other_products)")
     ap.add_argument("--no-other-products", action="store_true", help="skip the leg that times the other products mode (profiling passes: one arithmetic per run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not bracket kernels with HIP events")
@@ -95,8 +103,6 @@ def measured_traffic(encoder, T, image_hw, clips=1, which="gemm", products="f32"
     if image_hw[0] != image_hw[1] or clips != 1:
         return None, None
     want = {"encoder": encoder, "T": T, "image": image_hw[0]}
-    if products != "f32":
-        return None, None  # the committed passes are of the fp32 kernels
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_*_traffic.json"))):
         try:
             with open(path) as f:
@@ -104,15 +110,19 @@ def measured_traffic(encoder, T, image_hw, clips=1, which="gemm", products="f32"
         except (OSError, ValueError):
             continue
         cfg = dict(rec.get("config") or {})
-        if cfg.pop("products", "f32") != "f32" or cfg != want or "per_class" not in rec:
+        if cfg.pop("products", "f32") != products or cfg != want or "per_class" not in rec:
             continue
         pc = rec["per_class"]
         if which == "gemm" and pc.get("gemm"):
             return {"traffic_bytes_per_launch": pc["gemm"]["traffic_bytes_per_launch"]}, os.path.relpath(path, ROOT)
+        if which == "gemm_x6" and pc.get("gemm_x6"):
+            return {"traffic_bytes_per_launch": pc["gemm_x6"]["traffic_bytes_per_launch"]}, os.path.relpath(path, ROOT)
         if which == "attn" and pc.get("attn"):
             return {"traffic_bytes_per_launch": rec["attn_call_traffic_bytes"]}, os.path.relpath(path, ROOT)
         if which == "hbm":
             return {"traffic_bytes_per_launch": {k: (v["traffic_bytes_per_launch"] if v else None) for k, v in pc.items()}}, os.path.relpath(path, ROOT)
+    if products != "f32":
+        return None, None
     for rnd in ("r02", "r01"):
         path = os.path.join(ROOT, "profiles", f"{rnd}_{which}_traffic.json")
         try:
@@ -373,12 +383,30 @@ def main():
                                                 "avg_launch_ms": round(ms_e / n_e, 4), "flop_per_launch": round(fl_e / n_e, 1),
                                                 "share_of_linear_flop": round(fl_e / fl_l, 4)}
         if roofline is not None and model.products == "bf16x6" and n_e > 0 and ms_e > 0:
-            # the encoder's linears ran on the bf16 pipe: six bf16 MFMA FLOP per algorithmic FLOP, priced against the dense bf16 peak
-            ex = 6.0 * fl_e / (ms_e * 1e-3) / 1e12
-            roofline["encoder_launches"].update({"kernel": "gemm_x6_kernel", "executed_bf16_tflops": round(ex, 1), "peak_bf16_dense": PEAK_BF16_MFMA_TFLOPS,
-                                                 "frac_of_bf16_peak": round(ex / PEAK_BF16_MFMA_TFLOPS, 4),
-                                                 "note": "achieved / frac above are fp32-equivalent (algorithmic) TFLOP/s against the fp32 pipe's 157.3: "
-                                                         "above 1.0 means faster than any fp32-MFMA kernel can be"})
+            # The dominant kernel is gemm_x6_kernel: the encoder's linears run their products on the bf16 pipe, six bf16 MFMA FLOP per algorithmic FLOP.
+            # The physical bound is the dense bf16 MFMA peak, priced on the EXECUTED FLOP; the fp32-equivalent rate (what the model sees) is given
+            # beside it against the fp32 pipe's peak -- above 1.0 there means faster than any fp32-MFMA kernel can be.  The head's fp32 GEMMs keep
+            # their own object.
+            t_e = ms_e * 1e-3
+            ex = 6.0 * fl_e / t_e / 1e12
+            rec, src = measured_traffic(args.encoder, T, (SH, SW), Bc, "gemm_x6", "bf16x6")
+            head = dict(roofline)
+            head.pop("encoder_launches", None)
+            if n_h > 0 and ms_h > 0:
+                ach_h = fl_h / (ms_h * 1e-3) / 1e12
+                head.update({"kernel": "gemm_dma_kernel (patch embed + the DPT head's F.linear / 1x1 convs: fp32 products)", "achieved": round(ach_h, 2),
+                             "frac": round(ach_h / PEAK_F32_MFMA_TFLOPS, 4), "launches": n_h, "avg_launch_ms": round(ms_h / n_h, 4),
+                             "flop_per_launch": round(fl_h / n_h, 1), "algorithmic_bytes_per_launch": round(by_h / n_h, 1), "traffic": None, "traffic_unit": None})
+            roofline = {"kernel": "gemm_x6_kernel (qkv, proj, fc1, fc2 of the encoder blocks: fp32 in / out / accumulate, products as six bf16 MFMAs on three-term "
+                                  "bf16 splits of both operands)",
+                        "bound": "mfma", "achieved": round(ex, 1), "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ex / PEAK_BF16_MFMA_TFLOPS, 4),
+                        "traffic": None if rec is None else rec["traffic_bytes_per_launch"],
+                        "traffic_unit": None if rec is None else f"bytes per launch (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, {src}; separate --pmc passes of this command)",
+                        "algorithmic_bytes_per_launch": round(by_e / n_e, 1), "launches": n_e, "avg_launch_ms": round(ms_e / n_e, 4),
+                        "flop_per_launch": round(6.0 * fl_e / n_e, 1), "peak_dtype": "bf16 MFMA (v_mfma_f32_32x32x16_bf16), dense (never the 2:1-sparsity figure)",
+                        "fp32_equivalent": {"achieved": round(fl_e / t_e / 1e12, 2), "frac_of_fp32_mfma_peak": round(fl_e / t_e / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                            "flop_per_launch": round(fl_e / n_e, 1)},
+                        "head_linears_fp32": head}
         n, ms = model.profile_read("attn_spatial")
         D, depth, heads = DIMS[args.encoder]
         ntok = (SH // 14) * (SW // 14) + 1
@@ -386,13 +414,22 @@ def main():
         if n > 0 and ms > 0:
             achieved = flops / (ms / n * 1e-3) / 1e12
             rec, src = measured_traffic(args.encoder, T, (SH, SW), Bc, "attn")  # (the attention kernel is the same in both products modes)
-            roofline_attn = {"kernel": "attn_lean_kernel + attn_combine_kernel (one encoder-block attention call)", "bound": "mfma",
-                             "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None if rec is None else rec["traffic_bytes_per_launch"],
+            x6a = model.products == "bf16x6" and os.environ.get("EDV_X6_ATTN", "1") != "0" and ntok > 128
+            peak_a = PEAK_BF16_MFMA_TFLOPS if x6a else PEAK_F32_MFMA_TFLOPS
+            fp32_eq = achieved
+            if x6a:
+                achieved *= 6.0  # executed bf16 FLOP
+                rec, src = measured_traffic(args.encoder, T, (SH, SW), Bc, "attn", "bf16x6")
+            roofline_attn = {"kernel": ("attn_x6_kernel" if x6a else "attn_lean_kernel") + " + attn_combine_kernel (one encoder-block attention call)", "bound": "mfma",
+                             "achieved": round(achieved, 2), "peak": peak_a, "unit": "TFLOP/s",
+                             "frac": round(achieved / peak_a, 4), "traffic": None if rec is None else rec["traffic_bytes_per_launch"],
                              "traffic_unit": None if rec is None else f"bytes per call (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, {src})",
                              "algorithmic_bytes_per_launch": 4.0 * ntok * T * Bc * heads * 64 * 4,
-                             "launches": n, "avg_launch_ms": round(ms / n, 4), "flop_per_launch": flops,
-                             "peak_dtype": "f32 MFMA (v_mfma_f32_32x32x2_f32), dense"}
+                             "launches": n, "avg_launch_ms": round(ms / n, 4), "flop_per_launch": flops * (6.0 if x6a else 1.0),
+                             "peak_dtype": "bf16 MFMA (v_mfma_f32_32x32x16_bf16), dense" if x6a else "f32 MFMA (v_mfma_f32_32x32x2_f32), dense"}
+            if x6a:
+                roofline_attn["fp32_equivalent"] = {"achieved": round(fp32_eq, 2), "frac_of_fp32_mfma_peak": round(fp32_eq / PEAK_F32_MFMA_TFLOPS, 4),
+                                                    "flop_per_launch": flops}
         roofline_hbm = hbm_roofline(model, args.encoder, T, (SH, SW), Bc)
     # PCIe-inclusive variant (never `value`): pinned host clip -> HBM on a copy stream while the previous clip computes, forward, the four
     # maps -> pinned host memory on a second copy stream (endodav_amd/pipeline.py); the reference does both transfers synchronously
@@ -419,6 +456,7 @@ def main():
             "value": round(value, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            "precision": PRECISION_NOTE[model.products],
             "config": {"workload": f"ViT-{args.encoder[-1].upper()} endodav (features {kwargs['features']}, out_channels {kwargs['out_channels']}, "
                                    f"{args.lora} r=4, {'conv head' if args.conv_head else 'VDA head'}), {Bc} synthetic {SH}x{SW} T={T} clip(s) per GPU per step "
                                    "(BASELINE.json configs[1] shape at the defaults), hash-initialised weights", "encoder": args.encoder, "T": T,

@@ -39,7 +39,7 @@ INTERP_LEN = 8
 # a 257-row pos_embed: SURVEY.md §7 "drop-in quirks"); taps endodav.py:76-79; vitb from
 # models/endodac/endodac.py:184-199.
 PRODUCTS = {"f32": 0, "bf16x6": 1}  # EDV_PRODUCTS_* of include/endodav_hip.h
-PRODUCTS_DEFAULT = "f32"
+PRODUCTS_DEFAULT = "bf16x6"  # round 3: inference default (training forwards always run "f32")
 
 ENCODERS = {
     "vits": (384, 12, 6, 518, (2, 5, 8, 11)),

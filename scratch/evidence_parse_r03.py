@@ -9,7 +9,7 @@ O, name, args = sys.argv[1], sys.argv[2], sys.argv[3:]
 def cls(k):
     if "gemm_x6_kernel" in k: return "gemm_x6"
     if "gemm_dma_kernel" in k: return "gemm"
-    if "attn_lean_kernel" in k or "attn_spatial_kernel" in k: return "attn"
+    if "attn_lean_kernel" in k or "attn_spatial_kernel" in k or "attn_x6_kernel" in k: return "attn"
     if "attn_combine" in k: return "attn_combine"
     if "layernorm_kernel" in k: return "layernorm"
     if "groupnorm" in k: return "groupnorm"

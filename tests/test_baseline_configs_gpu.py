@@ -42,9 +42,10 @@ def _report(tag, out, ref):
 
 # ---------------------------------------------------------------------------------------------------------------------------------
 # config 3
-def test_config3_vitb_518_t16_matches_the_reference_golden(cuda):
-    model, kwargs, x, out = run_hip("vitb_518_t16", cuda)
-    assert model.launch_count() > 0
+@pytest.mark.parametrize("products", ["bf16x6", "f32"])
+def test_config3_vitb_518_t16_matches_the_reference_golden(cuda, products):
+    model, kwargs, x, out = run_hip("vitb_518_t16", cuda, products=products)
+    assert model.launch_count() > 0 and model.products == products
     check_against_golden("vitb_518_t16", out, "strided")
 
 
@@ -122,10 +123,11 @@ def test_config5_vitl_widths_t32_small_grid_matches_the_reference_golden(cuda):
     check_against_golden("vitl_126x182_t32", out, "strided")
 
 
-def test_config5_vitl_518_t32_matches_the_reference_golden(cuda):
+@pytest.mark.parametrize("products", ["bf16x6", "f32"])
+def test_config5_vitl_518_t32_matches_the_reference_golden(cuda, products):
     """The whole of config 5 against the reference run at full size in the build container (every 7th pixel of each scale and
-    per-frame statistics over all pixels)."""
-    model, _, _, out = run_hip("vitl_518_t32", cuda)
+    per-frame statistics over all pixels), in both products modes."""
+    model, _, _, out = run_hip("vitl_518_t32", cuda, products=products)
     check_against_golden("vitl_518_t32", out, "strided")
     print(f"\n[config 5: vitl 518 T=32] {model.launch_count()} launches, {model.device_bytes() / 2 ** 30:.2f} GiB")
 

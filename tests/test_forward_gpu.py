@@ -28,9 +28,14 @@ ABS_REL_MAX = 1e-4  # G2
 MICRO = [n for n in CASES if n.startswith("micro_")]
 
 
-def run_hip(name, cuda, capture=False):
+PRODUCTS = ["bf16x6", "f32"]  # both arithmetic modes of the encoder (endodav_amd/endodav.py: model.products)
+
+
+def run_hip(name, cuda, capture=False, products=None):
     model, kwargs, shape, kind, store = H.build_model(name)
     model = model.to(cuda)
+    if products is not None:
+        model.products = products
     model.set_capture(capture)
     x = H.case_input(name).to(cuda)
     with torch.no_grad():
@@ -62,15 +67,17 @@ def check_against_golden(name, out, store, all_pixels=False):
             assert naive <= DEPTH_RTOL, f"{name} disp{s}: all-pixel depth relative error {naive:.3e}"
 
 
+@pytest.mark.parametrize("products", PRODUCTS)
 @pytest.mark.parametrize("name", MICRO)
-def test_micro_cases_match_reference_golden(cuda, name):
-    _, _, _, out = run_hip(name, cuda)
+def test_micro_cases_match_reference_golden(cuda, name, products):
+    _, _, _, out = run_hip(name, cuda, products=products)
     check_against_golden(name, out, "full")
 
 
+@pytest.mark.parametrize("products", PRODUCTS)
 @pytest.mark.parametrize("name", ["vits_224x280_t2", "vits_224x280_conv_t2", "vits_518_t4", "resblock_224x280"])
-def test_full_size_cases_match_reference_golden(cuda, name):
-    _, _, _, out = run_hip(name, cuda)
+def test_full_size_cases_match_reference_golden(cuda, name, products):
+    _, _, _, out = run_hip(name, cuda, products=products)
     check_against_golden(name, out, "strided", all_pixels=True)
 
 
@@ -109,7 +116,7 @@ def test_stages_against_oracle(cuda, name):
 
 
 def test_baseline_config_vits_518_t8_against_oracle(cuda):
-    """BASELINE config 2 (ViT-S, 518x518, T=8) at full size: HIP vs the CPU oracle on this box,
+    """BASELINE config 2 (ViT-S, 518x518, T=8) at full size: HIP vs the CPU oracle on this box, in BOTH products modes,
     and the BASELINE quality metric abs_rel of build depth against reference depth."""
     import endodav_amd
     from endodav_amd import synth
@@ -122,16 +129,18 @@ def test_baseline_config_vits_518_t8_against_oracle(cuda):
     with torch.no_grad():
         ref = orc.forward(sd, x, H.oracle_config(kwargs))
     model = model.to(cuda)
-    with torch.no_grad():
-        out = model(x.to(cuda))
-    for s in range(4):
-        a, b = out[("disp", s)].cpu().numpy(), ref[("disp", s)].numpy()
-        assert a.shape == b.shape
-        e, ar, naive = H.rel_err(a, b), H.abs_rel(a, b), H.depth_rel_err(a, b)
-        de, excl = H.depth_gate(a, b)
-        print(f"\n[vits 518 T=8] disp{s}: scale-rel {e:.2e}, abs_rel {ar:.2e}, max depth rel {de:.2e} "
-              f"({excl:.2%} of pixels under the 1% floor; all-pixel figure {naive:.2e})")
-        assert e <= DISP_RTOL and de <= DEPTH_RTOL and ar <= ABS_REL_MAX
+    for products in PRODUCTS:
+        model.products = products
+        with torch.no_grad():
+            out = model(x.to(cuda))
+        for s in range(4):
+            a, b = out[("disp", s)].cpu().numpy(), ref[("disp", s)].numpy()
+            assert a.shape == b.shape
+            e, ar, naive = H.rel_err(a, b), H.abs_rel(a, b), H.depth_rel_err(a, b)
+            de, excl = H.depth_gate(a, b)
+            print(f"\n[vits 518 T=8, {products}] disp{s}: scale-rel {e:.2e}, abs_rel {ar:.2e}, max depth rel {de:.2e} "
+                  f"({excl:.2%} of pixels under the 1% floor; all-pixel figure {naive:.2e})")
+            assert e <= DISP_RTOL and de <= DEPTH_RTOL and ar <= ABS_REL_MAX
 
 
 @pytest.mark.parametrize("encoder,head,image_shape,clip,input_hw,opts", [

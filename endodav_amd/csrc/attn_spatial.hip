@@ -590,6 +590,9 @@ __global__ __launch_bounds__(X6_NW * 64) void attn_x6_kernel(const float *__rest
         const float *base = fbase + head * HD;
         const int qi = qt * QB + wave * 32 + l31;
         const int qrow = qi < N ? qi : N - 1;
+        // a wave whose 32 queries all lie past the sequence end (the last 256-query block of N = 1370 holds 90) stages and meets the barriers but
+        // computes nothing: its SIMD's matrix pipe goes to the partner wave
+        const bool wact = qt * QB + __builtin_amdgcn_readfirstlane(wave) * 32 < N;
 
         // Q^T planes (B operand of S^T): dims 16 s + 8 lh .. + 7 of this lane's query, pre-scaled, split
         xbf8 qb[3][4];
@@ -650,6 +653,7 @@ __global__ __launch_bounds__(X6_NW * 64) void attn_x6_kernel(const float *__rest
             asm volatile("" ::: "memory");
             if (t + 1 < kt1) load_tile(t + 1, treg);
             const unsigned char *stg = xsm + ST * X6_STAGE;
+            if (wact) {
             // ---- S^T - m = K Q^T - m
             f32x16 s0, s1;
             const float init = FIRST ? 0.f : -m_run;
@@ -727,6 +731,7 @@ __global__ __launch_bounds__(X6_NW * 64) void attn_x6_kernel(const float *__rest
                     o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vb[PA[tt]], pb[PB[tt]], o1, 0, 0, 0);
                 }
             }
+            }  // wact
             // tile t + 1: split what was loaded meanwhile and write it into the other stage (last read during tile t - 1: everybody passed this
             // tile's barrier since)
             if (t + 1 < kt1) split_store(treg, ST ^ 1);
@@ -749,7 +754,9 @@ __global__ __launch_bounds__(X6_NW * 64) void attn_x6_kernel(const float *__rest
         const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
         float inv = 1.0f / l_tot;
         float *orow = nullptr;
-        if (part) {
+        if (!wact) {
+            // (rows past the sequence end: the combine kernel never reads them)
+        } else if (part) {
             const int ql = wave * 32 + l31;
             orow = part + ql * HD;
             inv = 1.0f;

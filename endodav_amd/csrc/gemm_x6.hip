@@ -28,6 +28,11 @@
 
 #include "gemm_common.hpp"
 
+// Timeline hook for scratch/ubench/gemm_x6_trace.hip; expands to nothing in the product build.
+#ifndef EDV_X6_STAMP
+#define EDV_X6_STAMP(slot)
+#endif
+
 namespace edv {
 namespace {
 
@@ -118,6 +123,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const GemmDesc g, const
         const long long m0 = (long long)tm * XBM;
         const int n0 = tn * XBN;
 
+        EDV_X6_STAMP(0);
         // ---- staging roles ----
         // W: 12 DMA instructions per stage (3 planes x 4 groups of 32 rows), three per wave; lane i fills 16-byte chunk i of the 1 KB an instruction writes
         unsigned vw[3];
@@ -201,6 +207,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const GemmDesc g, const
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        EDV_X6_STAMP(1);
 
         // one step out of stage ST (compile-time): W DMA and A conversion of step + 2 into the stage read last step, A loads of step + 3, 12 fragment reads, 24 MFMAs
         auto step = [&](int kt, auto st_tag) {
@@ -246,6 +253,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const GemmDesc g, const
             if (kt + 1 < kt1) step(kt + 1, std::integral_constant<int, 1>{});
         }
 
+        EDV_X6_STAMP(2);
         bool store_tile = true;
         if (SPLIT && part) {
             // piece hand-off: the protocol of gemm_dma.hip (sc1 stores, every wave's vmcnt(0), barrier, one agent-scope counter add; the last arriver
@@ -307,6 +315,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const GemmDesc g, const
                     gemm_epilogue_buf<ACT>(g, acc[i][j], c1, m0 + (wave_s >> 1) * 64 + i * 32, n0 + (wave_s & 1) * 64 + j * 32, l31, lh);
                 }
         }
+        EDV_X6_STAMP(3);
     }
 }
 

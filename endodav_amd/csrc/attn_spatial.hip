@@ -651,6 +651,7 @@ __global__ __launch_bounds__(X6_NW * 64) void attn_x6_kernel(const float *__rest
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
             if (t + 1 < kt1) load_tile(t + 1, treg);
             const unsigned char *stg = xsm + ST * X6_STAGE;
             if (wact) {

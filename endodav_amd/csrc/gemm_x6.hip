@@ -210,13 +210,14 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const GemmDesc g, const
         EDV_X6_STAMP(1);
 
         // one step out of stage ST (compile-time): W DMA and A conversion of step + 2 into the stage read last step, A loads of step + 3, 12 fragment reads, 24 MFMAs
-        auto step = [&](int kt, auto st_tag) {
+        // FULL: a step in the steady state (kt + 5 < kt1): every staging action happens, in ONE basic block, and the schedule is spelled out -- the
+        // conversion of A(kt + 2) (about 70 VALU instructions) and its six ds_write_b64 go BETWEEN the 24 MFMAs, three VALU per MFMA: the bf16 MFMA
+        // holds the issue port for 8 of its 32 cycles, so the fillers are free there, while as a burst in front of the MFMAs they were a third of the
+        // step (timeline of scratch/ubench/gemm_x6_trace.hip: 0.89 us per step for a workgroup alone on its CU against 0.35 us of MFMA time).
+        auto step = [&](int kt, auto st_tag, auto full_tag) {
             constexpr int ST = decltype(st_tag)::value, S2 = (ST + 2) % XNST;
-            if (kt + 2 < kt1) {
-                issue_w(kt + 2, S2);
-                split_store_a(aset[ST], S2);  // A(kt + 2), loaded three steps ago
-                if (kt + 5 < kt1) load_a(kt + 5, aset[ST]);
-            }
+            constexpr bool FULL = decltype(full_tag)::value;
+            if (FULL || kt + 2 < kt1) issue_w(kt + 2, S2);
             bf16x8 a[2][3], b[2][3];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -225,6 +226,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const GemmDesc g, const
                     a[i][p] = *reinterpret_cast<const bf16x8 *>(smem + ST * XSTAGE + fa[i] + p * XPLANE);
                     b[i][p] = *reinterpret_cast<const bf16x8 *>(smem + ST * XSTAGE + fb[i] + p * XPLANE);
                 }
+            if (FULL || kt + 2 < kt1) split_store_a(aset[ST], S2);  // A(kt + 2), loaded three steps ago
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // smallest terms first
 #pragma unroll
             for (int t = 0; t < 6; ++t)
@@ -232,25 +234,45 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const GemmDesc g, const
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[j][PB[t]], acc[i][j], 0, 0, 0);
+            if (FULL || kt + 5 < kt1) load_a(kt + 5, aset[ST]);
+            if (FULL) {
+                __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);  // the fragment reads first
+#pragma unroll
+                for (int i = 0; i < 24; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);  // three VALU
+                    if ((i & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // a plane write after every fourth
+                }
+            }
             // W of step + 1 (issued one step ago) has landed: younger than it are A(step + 4) x2, W(step + 2) x3, A(step + 5) x2.  The wave's own LDS writes
             // and fragment reads are done (lgkmcnt) before the barrier that publishes the stage written and releases the stage read.
-            if (kt + 5 < kt1)
+            // (sched_barrier on both sides: with the schedule spelled out above the machine scheduler otherwise moved the NEXT step's fragment reads above
+            // these waits and the barrier -- reads of a stage other waves' DMAs have not yet been waited for.  The inline asm's memory clobber does not
+            // stop it; tests/test_isa_barriers_cpu.py::test_x6_stage_reads_stay_behind_their_barrier checks the disassembly.)
+            __builtin_amdgcn_sched_barrier(0);
+            if (FULL || kt + 5 < kt1)
                 asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
         };
         {
             int kt = kt0;
-            for (; kt + 2 < kt1; kt += 3) {
-                step(kt, std::integral_constant<int, 0>{});
-                step(kt + 1, std::integral_constant<int, 1>{});
-                step(kt + 2, std::integral_constant<int, 2>{});
+            for (; kt + 7 < kt1; kt += 3) {  // kt + 2 + 5 < kt1: all three steps are full
+                step(kt, std::integral_constant<int, 0>{}, std::true_type{});
+                step(kt + 1, std::integral_constant<int, 1>{}, std::true_type{});
+                step(kt + 2, std::integral_constant<int, 2>{}, std::true_type{});
             }
-            if (kt < kt1) step(kt, std::integral_constant<int, 0>{});
-            if (kt + 1 < kt1) step(kt + 1, std::integral_constant<int, 1>{});
+            for (; kt + 2 < kt1; kt += 3) {
+                step(kt, std::integral_constant<int, 0>{}, std::false_type{});
+                step(kt + 1, std::integral_constant<int, 1>{}, std::false_type{});
+                step(kt + 2, std::integral_constant<int, 2>{}, std::false_type{});
+            }
+            if (kt < kt1) step(kt, std::integral_constant<int, 0>{}, std::false_type{});
+            if (kt + 1 < kt1) step(kt + 1, std::integral_constant<int, 1>{}, std::false_type{});
         }
 
         EDV_X6_STAMP(2);

@@ -97,11 +97,13 @@ def waits(i: Inst):
     return (int(v.group(1)) if v else None), (int(l.group(1)) if l else None)
 
 
-def barrier_violations(insts: List[Inst], loops_only: bool = True) -> List[str]:
-    """Every s_barrier (inside a loop when `loops_only`) must find, scanning backwards to the previous barrier, an `s_waitcnt vmcnt(0)` with no
-    vector-memory instruction after it and an `s_waitcnt lgkmcnt(0)` with no LDS instruction after it.  A stretch between two barriers that
-    issues no LDS-DMA needs no vmcnt wait, one that issues no LDS access needs no lgkmcnt wait.  The scan is linear in address order: the
-    compiler keeps the k-loop bodies of these kernels straight-line."""
+def barrier_violations(insts: List[Inst], loops_only: bool = True, ring: bool = False) -> List[str]:
+    """Every s_barrier (inside a loop when `loops_only`) must find, scanning backwards to the previous barrier, a vector-memory wait that leaves no
+    LDS-DMA of an EARLIER stretch in flight, and an `s_waitcnt lgkmcnt(0)` with no LDS instruction after it.  The memory wait is either `vmcnt(0)` with no
+    LDS-DMA after it (the two-stage kernels: the only form accepted unless `ring`), or, for `ring` kernels, a counted `vmcnt(N)`: the N youngest vector-memory instructions before it may then still be in flight,
+    and those may include LDS-DMAs of the CURRENT stretch only (gemm_x6's three-stage ring: the DMA issued in a step fills the stage read two barriers
+    later; what must have landed is the DMA of the step before).  A stretch that issues no LDS-DMA and inherits none needs no vmcnt wait, one that issues
+    no LDS access needs no lgkmcnt wait.  The scan is linear in address order: the compiler keeps the k-loop bodies of these kernels straight-line."""
     loops = loop_ranges(insts)
     bad = []
     for n, i in enumerate(insts):
@@ -109,25 +111,47 @@ def barrier_violations(insts: List[Inst], loops_only: bool = True) -> List[str]:
             continue
         if loops_only and not any(lo <= i.addr <= hi for lo, hi in loops):
             continue
-        need_v = need_l = True   # still looking for the wait
-        dirty_v = dirty_l = False  # an un-waited access seen (scanning backwards) before the wait
+        need_l = True
+        dirty_l = False
+        wait_at, wait_n = None, None  # the last vmcnt wait of the stretch
+        prev_barrier = -1
         for j in range(n - 1, -1, -1):
             p = insts[j]
             if p.op == "s_barrier":
+                prev_barrier = j
                 break
             v, l = waits(p)
-            if need_v and v == 0:
-                need_v = False
             if need_l and l == 0:
                 need_l = False
-            if need_v and is_lds_dma(p):
-                dirty_v = True
             if need_l and is_lds_access(p):
                 dirty_l = True
-            if not need_v and not need_l:
-                break
-        if dirty_v:
-            bad.append(f"{i.addr:#x}: LDS-DMA in flight across s_barrier (no s_waitcnt vmcnt(0) after it)")
+            if wait_at is None and v is not None:
+                wait_at, wait_n = j, v
+        # vector-memory side
+        stretch = range(prev_barrier + 1, n)
+        dma_after_wait = any(is_lds_dma(insts[j]) for j in stretch if wait_at is None or j > wait_at)
+        if wait_at is None:
+            if any(is_lds_dma(insts[j]) for j in stretch):
+                bad.append(f"{i.addr:#x}: LDS-DMA in flight across s_barrier (no s_waitcnt vmcnt after it)")
+        elif not ring:
+            if wait_n != 0 and any(is_lds_dma(insts[j]) for j in stretch):
+                bad.append(f"{i.addr:#x}: LDS-DMA in flight across s_barrier (a counted s_waitcnt vmcnt({wait_n}) is not a drain)")
+            elif dma_after_wait:
+                bad.append(f"{i.addr:#x}: LDS-DMA in flight across s_barrier (issued after the s_waitcnt vmcnt(0))")
+        else:
+            if wait_n == 0 and dma_after_wait:
+                bad.append(f"{i.addr:#x}: LDS-DMA in flight across s_barrier (issued after the s_waitcnt vmcnt(0))")
+            # the wait_n youngest vector-memory instructions before the wait may be in flight: none of them may be an LDS-DMA of an earlier stretch
+            left = wait_n
+            for j in range(wait_at - 1, -1, -1):
+                if left == 0:
+                    break
+                p = insts[j]
+                if is_vmem(p):
+                    left -= 1
+                    if is_lds_dma(p) and j < prev_barrier:
+                        bad.append(f"{i.addr:#x}: s_waitcnt vmcnt({wait_n}) leaves the LDS-DMA at {p.addr:#x} (an earlier stretch) in flight across s_barrier")
+                        break
         if dirty_l:
             bad.append(f"{i.addr:#x}: LDS access in flight across s_barrier (no s_waitcnt lgkmcnt(0) after it)")
     return bad
@@ -170,5 +194,27 @@ def store_hazard_violations(insts: List[Inst]) -> List[str]:
                     bad.append(f"{p.addr:#x}: {p.op} writes {p.args.split(',')[0]} {slots} wait state(s) after {i.op} {i.args}")
                 slots += 1
             if slots >= 2:
+                break
+    return bad
+
+
+def reads_after_last_mfma(insts: List[Inst]) -> List[str]:
+    """For the multi-stage LDS rings of the bf16 x 6 kernels: in every stretch between two s_barriers that multiplies (contains MFMAs), no LDS READ may
+    follow the last MFMA.  A read there belongs to the NEXT stretch -- hoisted above the waits and the barrier that publish the stage it reads (other waves'
+    DMAs / plane writes); the machine scheduler did exactly that once the schedule of gemm_x6's steps was spelled out with sched_group_barrier, the inline
+    asm's memory clobber notwithstanding."""
+    bad = []
+    start = 0
+    for n, i in enumerate(insts):
+        if i.op != "s_barrier":
+            continue
+        seg = insts[start:n]
+        start = n + 1
+        last = max((k for k, p in enumerate(seg) if p.op.startswith("v_mfma")), default=None)
+        if last is None:
+            continue
+        for p in seg[last + 1:]:
+            if p.op.startswith("ds_read"):
+                bad.append(f"{p.addr:#x}: {p.op} after the last MFMA before the s_barrier at {i.addr:#x}")
                 break
     return bad

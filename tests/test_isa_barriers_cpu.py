@@ -46,6 +46,12 @@ def test_checker_on_synthetic_streams():
     assert any("LDS-DMA" in v for v in isa.barrier_violations(late, loops_only=False))  # the flat-address DMA form carries "lds" in the mnemonic
     late = [I("s_waitcnt", "vmcnt(0) lgkmcnt(0)"), I("buffer_load_dwordx4", "v1, s[8:11], s74 offen lds"), I("s_barrier")]
     assert any("LDS-DMA" in v for v in isa.barrier_violations(late, loops_only=False))
+    # ring kernels: a counted wait may leave the CURRENT stretch's DMAs in flight, never an earlier stretch's
+    ring_ok = [I("s_barrier"), I("buffer_load_dwordx4", "v1, s[8:11], s5 offen lds"), I("global_load_dwordx4", "v[0:3], v[8:9], off"), I("s_waitcnt", "vmcnt(0)"),
+               I("s_barrier"), I("buffer_load_dwordx4", "v1, s[8:11], s6 offen lds"), I("global_load_dwordx4", "v[0:3], v[8:9], off"), I("s_waitcnt", "vmcnt(2)"), I("s_barrier")]
+    assert isa.barrier_violations(ring_ok, loops_only=False, ring=True) == []
+    ring_bad = ring_ok[:3] + [I("s_waitcnt", "vmcnt(7)")] + ring_ok[4:7] + [I("s_waitcnt", "vmcnt(4)"), I("s_barrier")]
+    assert any("earlier stretch" in v for v in isa.barrier_violations(ring_bad, loops_only=False, ring=True))
     # a stretch without LDS traffic needs no wait; plain global loads may stay in flight across a barrier
     assert isa.barrier_violations([I("s_barrier"), I("global_load_dwordx4", "v[0:3], v[8:9], off"), I("v_add_f32", "v0, v1, v2"), I("s_barrier")], loops_only=False) == []
     # loop detection: a backward branch
@@ -65,7 +71,7 @@ def test_hot_kernels_are_present(kernels):
 def test_no_lds_traffic_in_flight_across_any_barrier(kernels):
     bad = {}
     for name, insts in kernels.items():
-        v = isa.barrier_violations(insts, loops_only=False)
+        v = isa.barrier_violations(insts, loops_only=False, ring="gemm_x6_kernel" in name)  # (a three-stage ring with counted waits)
         if v:
             bad[name] = v
     assert not bad, "\n".join(f"{n}: {v}" for n, v in bad.items())
@@ -85,3 +91,16 @@ def test_store_hazard_checker_on_hand_made_listings():
 def test_no_wide_store_with_register_soffset_is_followed_by_a_write_of_its_data(kernels):
     bad = {n: v for n, v in ((n, isa.store_hazard_violations(i)) for n, i in kernels.items()) if v}
     assert not bad, "\n".join(f"{n}: {v}" for n, v in bad.items())
+
+
+def test_x6_stage_reads_stay_behind_their_barrier(kernels):
+    """gemm_x6_kernel / attn_x6_kernel: no LDS read between a stretch's last MFMA and the barrier that ends it (tests/isa.py::reads_after_last_mfma)."""
+    x6 = {n: v for n, v in kernels.items() if "gemm_x6_kernel" in n or "attn_x6_kernel" in n}
+    assert len(x6) >= 7  # six GEMM instantiations + the attention
+    bad = {n: b for n, b in ((n, isa.reads_after_last_mfma(v)) for n, v in x6.items()) if b}
+    assert not bad, "\n".join(f"{n}: {v}" for n, v in bad.items())
+    # the checker itself, on the listing the scheduler produced before the sched_barrier pair went in
+    hoisted = [I("s_barrier"), I("ds_read_b128", "v[0:3], v9"), I("v_mfma_f32_32x32x16_bf16", "v[0:15], v[0:3], v[4:7], v[0:15]"), I("ds_read_b128", "v[4:7], v9 offset:24576"),
+               I("s_waitcnt", "lgkmcnt(0)"), I("s_barrier")]
+    assert len(isa.reads_after_last_mfma(hoisted)) == 1
+    assert isa.reads_after_last_mfma(hoisted[:3] + hoisted[4:]) == []

@@ -217,7 +217,12 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const GemmDesc g, const
         auto step = [&](int kt, auto st_tag, auto full_tag) {
             constexpr int ST = decltype(st_tag)::value, S2 = (ST + 2) % XNST;
             constexpr bool FULL = decltype(full_tag)::value;
+            // EDV_X6_NOSTAGE / _NOMFMA / _NOBARRIER / _NOWAIT: ablation builds of scratch/ubench/gemm_x6_trace.hip (wrong results, timing only).  A workgroup
+            // alone on its CU, K = 4096: 0.715 us per step; without the staging 0.503; with 4 MFMAs instead of 24 0.540; without the barrier 0.675; fragment
+            // reads + 24 MFMAs alone 0.474 = 24 x 32 cycles at 1.62 GHz, the clock the part holds under these MFMAs -- the matrix pipe's real rate here.
+#ifndef EDV_X6_NOSTAGE
             if (FULL || kt + 2 < kt1) issue_w(kt + 2, S2);
+#endif
             bf16x8 a[2][3], b[2][3];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -226,15 +231,24 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const GemmDesc g, const
                     a[i][p] = *reinterpret_cast<const bf16x8 *>(smem + ST * XSTAGE + fa[i] + p * XPLANE);
                     b[i][p] = *reinterpret_cast<const bf16x8 *>(smem + ST * XSTAGE + fb[i] + p * XPLANE);
                 }
+#ifndef EDV_X6_NOSTAGE
             if (FULL || kt + 2 < kt1) split_store_a(aset[ST], S2);  // A(kt + 2), loaded three steps ago
+#endif
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // smallest terms first
+#ifdef EDV_X6_NOMFMA
+            constexpr int NT = 1;  // one MFMA per accumulator keeps the fragment reads alive
+#else
+            constexpr int NT = 6;
+#endif
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int t = 6 - NT; t < 6; ++t)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[j][PB[t]], acc[i][j], 0, 0, 0);
+#ifndef EDV_X6_NOSTAGE
             if (FULL || kt + 5 < kt1) load_a(kt + 5, aset[ST]);
+#endif
             if (FULL) {
                 __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);  // the fragment reads first
 #pragma unroll
@@ -250,12 +264,18 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(const GemmDesc g, const
             // these waits and the barrier -- reads of a stage other waves' DMAs have not yet been waited for.  The inline asm's memory clobber does not
             // stop it; tests/test_isa_barriers_cpu.py::test_x6_stage_reads_stay_behind_their_barrier checks the disassembly.)
             __builtin_amdgcn_sched_barrier(0);
+#ifdef EDV_X6_NOWAIT  // (ablation, wrong results) is the W DMA's latency what a step waits for?  No: 18.3 us per 24-step k loop either way
+            asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+#else
             if (FULL || kt + 5 < kt1)
                 asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#ifndef EDV_X6_NOBARRIER
             __builtin_amdgcn_s_barrier();
+#endif
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         };

@@ -2080,8 +2080,10 @@ int edv_refresh_lora(edv_ctx *ctx, void *stream) {
 int edv_set_products(edv_ctx *ctx, int32_t products, void *stream) {
     EDV_CHECK(ctx, "null context");
     EDV_CHECK(products == EDV_PRODUCTS_F32 || products == EDV_PRODUCTS_BF16X6, "products: EDV_PRODUCTS_F32 or EDV_PRODUCTS_BF16X6");
+    const bool turned_on = products == EDV_PRODUCTS_BF16X6 && ctx->products != EDV_PRODUCTS_BF16X6;
     ctx->products = products;
-    if (products == EDV_PRODUCTS_BF16X6 && ctx->prepared && ctx->x6.empty()) {
+    if (turned_on && ctx->prepared) {  // planes are kept current only while the mode is on (edv_prepare / edv_refresh_lora): rebuild, never reuse
+        ctx->x6.clear();
         Run r(ctx, (hipStream_t)stream);
         return r.build_x6(false);
     }

@@ -13,9 +13,15 @@ NCCL(RCCL) traffic is the barrier and the MAX-reduction of the elapsed time arou
 (``endodav_amd.parallel.timed_region``, the same code the gloo world-2 test runs).
 
 Rank 0 prints ONE JSON line: value = total frames of all ranks / max-over-ranks time, plus
-  roofline            the dominant kernel class by time -- the dense fp32-MFMA GEMM (every F.linear / 1x1 conv) -- priced as
-                      algorithmic FLOP over launch time, measured with HIP event pairs on the launch stream inside the timed region
-  roofline_attention  the second one: the encoder's fused spatial attention, same method
+  precision           what "dtype f32" means in the run's products mode (model.products; --products): fp32 tensors / accumulation / softmax / norms / head
+                      always; in the default mode ("bf16x6") the encoder's linears and attention form each fp32 product as six bf16 MFMAs on three-term
+                      bf16 splits of both operands (error against fp64 no worse than the fp32 matrix pipe's: tests/test_gemm_x6_gpu.py, test_attn_x6_gpu.py)
+  other_products      the OTHER products mode timed in the same process on the same clip (value, and how far the two modes' disparities are apart)
+  roofline            the dominant kernel by time, priced as FLOP over kernel time measured with HIP event pairs inside the dispatches in the first steps
+                      of the timed region: default mode -- gemm_x6_kernel, EXECUTED bf16 FLOP (6 x algorithmic) against the dense bf16 MFMA peak, with the
+                      fp32-equivalent rate against the fp32 MFMA peak beside it and the head's fp32 GEMMs as `head_linears_fp32`; --products f32 -- the
+                      dense fp32-MFMA GEMM class (every F.linear / 1x1 conv) against the fp32 MFMA peak, its encoder launches as `encoder_launches`
+  roofline_attention  the second one: the encoder's fused spatial attention, same method (attn_x6_kernel / attn_lean_kernel)
   roofline_hbm        the bandwidth-bound kernels (LayerNorm, GroupNorm, bilinear resamples, GEGLU, the final 1x1 convolution,
                       patchify): algorithmic bytes over launch time against the 8 TB/s HBM3E peak
   cpu_baseline        the oracle (PyTorch-CPU restatement, kind "port") timed on this box's host cores on a bounded

@@ -86,3 +86,23 @@ def test_attn_x6_workspace_contract(lib, cuda):
     o = torch.empty(Fr * N, heads * 64, device=cuda)
     assert lib.edv_attn_spatial_x6(qd.data_ptr(), o.data_ptr(), Fr, N, heads, None, 0, st()) != 0
     assert "workspace" in lib.edv_last_error().decode()
+
+
+def test_attn_x6_random_geometries(lib, cuda):
+    """Twenty seeded random (frames, tokens, heads) with ragged query blocks and key tiles, NaN guard bands around the output."""
+    g = torch.Generator().manual_seed(77)
+    for case in range(20):
+        Fr = int(torch.randint(1, 7, (1,), generator=g))
+        N = int(torch.randint(129, 900, (1,), generator=g))
+        heads = int(torch.randint(1, 9, (1,), generator=g))
+        D = heads * 64
+        qkv = rnd(Fr * N, 3 * D, seed=600 + case, scale=2.0)
+        ref = reference(qkv, Fr, N, heads)
+        qd = qkv.to(cuda)
+        guard = 32
+        buf = torch.full((Fr * N + 2 * guard, D), float("nan"), device=cuda)
+        o = buf[guard:guard + Fr * N]
+        attn_x6(lib, cuda, qd, o, Fr, N, heads)
+        torch.cuda.synchronize()
+        assert torch.isnan(buf[:guard]).all() and torch.isnan(buf[guard + Fr * N:]).all(), f"case {case}: F={Fr} N={N} heads={heads} wrote outside its rows"
+        close(o, ref, 5e-6, f"attn_x6 case {case}: F={Fr} N={N} heads={heads}")

@@ -133,3 +133,39 @@ def test_gemm_x6_rejects_what_it_does_not_cover(lib, cuda):
     assert lib.edv_gemm_x6(a.data_ptr(), p.data_ptr(), a.data_ptr(), 256, 256, 24, None, 0, None, None, None, 0, st()) != 0  # K % 16
     assert b"K % 16" in lib.edv_last_error()
     assert lib.edv_gemm_x6(a.data_ptr(), p.data_ptr(), a.data_ptr(), 256, 32, 16, None, 0, None, None, None, 0, st()) != 0  # N < 64
+
+
+def test_gemm_x6_random_geometries(lib, cuda):
+    """Forty seeded random shapes (ragged M and N, 1 .. 40 k-steps, every epilogue combination, with and without the stream-K workspace) against fp64."""
+    g = torch.Generator().manual_seed(2024)
+    ws, nbytes = gemm_ws(lib, cuda)
+    for case in range(40):
+        M = int(torch.randint(1, 3000, (1,), generator=g))
+        N = int(torch.randint(64, 700, (1,), generator=g))
+        K = 16 * int(torch.randint(1, 41, (1,), generator=g))
+        act = int(torch.randint(0, 3, (1,), generator=g))
+        flags = [bool(torch.randint(0, 2, (1,), generator=g)) for _ in range(4)]  # bias, gamma, residual, workspace
+        A, W = rnd(M, K, seed=100 + case), rnd(N, K, seed=200 + case, scale=1 / math.sqrt(K))
+        bias = rnd(N, seed=300 + case, scale=0.1) if flags[0] else None
+        gamma = rnd(N, seed=400 + case) + 1.2 if flags[1] else None
+        R = rnd(M, N, seed=500 + case) if flags[2] else None
+        ref = A.double() @ W.double().T
+        if bias is not None:
+            ref = ref + bias.double()
+        ref = F.gelu(ref) if act == 1 else (F.relu(ref) if act == 2 else ref)
+        if gamma is not None:
+            ref = ref * gamma.double()
+        if R is not None:
+            ref = ref + R.double()
+        d = lambda t: None if t is None else t.to(cuda)
+        Ad, Wd, bd, gd, Rd = d(A), d(W), d(bias), d(gamma), d(R)
+        planes = planes_of(lib, Wd, N, K)
+        guard = 64
+        buf = torch.full((M + 2 * guard, N), float("nan"), device=cuda)  # NaN guard bands of 64 rows on both sides
+        Cd = buf[guard:guard + M]
+        w, nb = (ws, nbytes) if flags[3] else (None, 0)
+        _lib.check(lib.edv_gemm_x6(Ad.data_ptr(), planes.data_ptr(), Cd.data_ptr(), M, N, K, _lib.ptr(bd), act, _lib.ptr(gd), _lib.ptr(Rd), _lib.ptr(w), nb, st()),
+                   f"edv_gemm_x6 case {case}: {M}x{N}x{K}")
+        torch.cuda.synchronize()
+        assert torch.isnan(buf[:guard]).all() and torch.isnan(buf[guard + M:]).all(), f"case {case}: {M}x{N}x{K} wrote outside its rows"
+        close(Cd, ref, 3e-6, f"gemm_x6 case {case}: {M}x{N}x{K} act {act} {flags}")

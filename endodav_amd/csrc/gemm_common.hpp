@@ -208,6 +208,10 @@ __device__ __forceinline__ void gemm_epilogue_fast(const GemmDesc &g, f32x16 (&a
 // Edge tiles need no second code path: the descriptors end at row M (num_records = M x ld x 4 bytes; the hardware range-checks voffset + soffset
 // as one sum without wrap-around -- scratch/ubench/buf_range.hip -- so stores to rows past M are dropped and loads return 0), and a lane whose
 // column is past N gets a per-lane offset near 2^32, which no scalar offset brings back into range.
+// cache policy of the output stores (aux bits of buffer_store: 0 = default, 2 = nt / streaming): A/B builds only
+#ifndef EDV_EPI_STORE_AUX
+#define EDV_EPI_STORE_AUX 0
+#endif
 template <int ACT>
 __device__ __forceinline__ void gemm_epilogue_buf(const GemmDesc &g, f32x16 &acc, const EpiCols<1> &cols, long long row0, int col0, int l31, int lh) {
     // row0 / col0: first row / column of the wave's block -- wave-uniform (callers derive them from readfirstlane(wave)), so they live in SGPRs
@@ -246,7 +250,7 @@ __device__ __forceinline__ void gemm_epilogue_buf(const GemmDesc &g, f32x16 &acc
         for (int e = 0; e < 2; ++e) {
             const int r = 2 * i + e;
             const float ve = e ? v[1] : v[0];  // (a bit_cast applied directly to the vector element v[e] compiles to element 0 for both e)
-            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ve), rc, (int)vo, (int)(so + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldc * 4)), 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ve), rc, (int)vo, (int)(so + (unsigned)(((r & 3) + 8 * (r >> 2)) * g.ldc * 4)), EDV_EPI_STORE_AUX);
         }
     }
 }

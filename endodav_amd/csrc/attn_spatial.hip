@@ -639,12 +639,18 @@ __global__ __launch_bounds__(X6_NW * 64) void attn_x6_kernel(const float *__rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) o0[r] = o1[r] = 0.f;
         float m_run = 0.f, l_run = 0.f;
-        f32x4 treg[4];
+        f32x4 treg[2][4];  // staging registers: set i holds the tile that goes to LDS stage i (loaded two tiles ahead of its use)
 
         constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};  // (tile-operand plane, register-operand plane), smallest terms first
-        auto tile = [&](int t, auto st_tag, auto first_tag) {
+        // FULL: a tile in the steady state (t + 2 < kt1): the conversion of tile t + 1 (about 100 VALU instructions and twelve plane writes) is spread
+        // under the 48 MFMAs of S^T by an explicit schedule (two VALU per MFMA, a write every fourth) instead of running as a burst at the tile's end,
+        // where the two waves of a SIMD -- in lockstep behind the same barrier -- run it at the same time.  Worth 1-4 %.  (Removing the staging
+        // altogether is worth 22 %, the softmax 6 %, the P split 8 %, all three 27 %: profiles/r03_notes.txt.  Under these MFMAs the part is
+        // power-bound at 1.65-1.8 GHz, so what the kernel pays for is the energy of those instructions, wherever they sit.)
+        auto tile = [&](int t, auto st_tag, auto first_tag, auto full_tag) {
             constexpr int ST = decltype(st_tag)::value;
             constexpr bool FIRST = decltype(first_tag)::value;
+            constexpr bool FULL = decltype(full_tag)::value;
             const int k0 = t * KT;
             // this wave's plane writes of tile t and its fragment reads of tile t - 1 are done; then everybody's are
             __builtin_amdgcn_sched_barrier(0);
@@ -652,9 +658,16 @@ __global__ __launch_bounds__(X6_NW * 64) void attn_x6_kernel(const float *__rest
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < kt1) load_tile(t + 1, treg);
+            // EDV_AX6_NOSTAGE / _NOSOFTMAX / _NOPSPLIT: ablation builds for scratch/attn_x6_time.py (wrong results, timing only; profiles/r03_notes.txt)
+#ifndef EDV_AX6_NOSTAGE
+            if (FULL || t + 2 < kt1) load_tile(t + 2, treg[ST]);  // set ST held tile t (in LDS since the previous tile); tile t + 2 goes to stage ST too
+#endif
             const unsigned char *stg = xsm + ST * X6_STAGE;
-            if (wact) {
+            if (!wact) {
+#ifndef EDV_AX6_NOSTAGE
+                if (FULL || t + 1 < kt1) split_store(treg[ST ^ 1], ST ^ 1);
+#endif
+            } else {
             // ---- S^T - m = K Q^T - m
             f32x16 s0, s1;
             const float init = FIRST ? 0.f : -m_run;
@@ -674,6 +687,24 @@ __global__ __launch_bounds__(X6_NW * 64) void attn_x6_kernel(const float *__rest
                     s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[PA[tt]], qb[PB[tt]][s2], s1, 0, 0, 0);
                 }
             }
+#ifndef EDV_AX6_NOSTAGE
+            // tile t + 1 (loaded during tile t - 1): split and written into the other stage, last read during tile t - 1 (everybody passed this tile's
+            // barrier since).  In source order after the MFMAs; FULL spells out where the instructions go.
+            if (FULL || t + 1 < kt1) split_store(treg[ST ^ 1], ST ^ 1);
+            if (FULL) {
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);  // this step's six fragment reads
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // two VALU of the conversion
+                        if ((i & 3) == 3) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // a plane write
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#endif
             if (k0 + KT > N) {
                 asm volatile("" ::: "memory");
 #pragma unroll
@@ -682,6 +713,7 @@ __global__ __launch_bounds__(X6_NW * 64) void attn_x6_kernel(const float *__rest
                     if (k0 + 32 + (r & 3) + 8 * (r >> 2) + 4 * lh >= N) s1[r] = -INFINITY;
                 }
             }
+#ifndef EDV_AX6_NOSOFTMAX
             float mx = fmaxf(s0[0], s1[0]), my = fmaxf(s0[8], s1[8]);
 #pragma unroll
             for (int r = 1; r < 8; ++r) {
@@ -711,15 +743,25 @@ __global__ __launch_bounds__(X6_NW * 64) void attn_x6_kernel(const float *__rest
                 psum += s0[r] + s1[r];
             }
             l_run += psum;
+#else
+            l_run += s0[0] + s1[15];
+#endif
             // ---- O^T += V^T P^T, 16 keys per step: registers 8 (j & 1) .. + 7 of sub-tile j >> 1, split into planes, are the B operand
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 xbf8 pb[3];
+#ifndef EDV_AX6_NOPSPLIT
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const Split3 sp = split3((j < 2 ? s0 : s1)[8 * (j & 1) + e]);
                     pb[0][e] = sp.p0; pb[1][e] = sp.p1; pb[2][e] = sp.p2;
                 }
+#else
+                {
+                    const f32x4 raw = {(j < 2 ? s0 : s1)[8 * (j & 1)], (j < 2 ? s0 : s1)[8 * (j & 1) + 1], (j < 2 ? s0 : s1)[8 * (j & 1) + 2], (j < 2 ? s0 : s1)[8 * (j & 1) + 3]};
+                    pb[0] = pb[1] = pb[2] = __builtin_bit_cast(xbf8, raw);
+                }
+#endif
                 xbf8 va[3], vb[3];
 #pragma unroll
                 for (int p2 = 0; p2 < 3; ++p2) {
@@ -733,20 +775,22 @@ __global__ __launch_bounds__(X6_NW * 64) void attn_x6_kernel(const float *__rest
                 }
             }
             }  // wact
-            // tile t + 1: split what was loaded meanwhile and write it into the other stage (last read during tile t - 1: everybody passed this
-            // tile's barrier since)
-            if (t + 1 < kt1) split_store(treg, ST ^ 1);
         };
-        load_tile(kt0, treg);
-        split_store(treg, 0);
-        tile(kt0, std::integral_constant<int, 0>{}, std::true_type{});
+        load_tile(kt0, treg[0]);
+        if (kt0 + 1 < kt1) load_tile(kt0 + 1, treg[1]);
+        split_store(treg[0], 0);
+        tile(kt0, std::integral_constant<int, 0>{}, std::true_type{}, std::false_type{});
         {
             int t = kt0 + 1;
-            for (; t + 1 < kt1; t += 2) {
-                tile(t, std::integral_constant<int, 1>{}, std::false_type{});
-                tile(t + 1, std::integral_constant<int, 0>{}, std::false_type{});
+            for (; t + 3 < kt1; t += 2) {  // (t + 1) + 2 < kt1: both tiles are full
+                tile(t, std::integral_constant<int, 1>{}, std::false_type{}, std::true_type{});
+                tile(t + 1, std::integral_constant<int, 0>{}, std::false_type{}, std::true_type{});
             }
-            if (t < kt1) tile(t, std::integral_constant<int, 1>{}, std::false_type{});
+            for (; t + 1 < kt1; t += 2) {
+                tile(t, std::integral_constant<int, 1>{}, std::false_type{}, std::false_type{});
+                tile(t + 1, std::integral_constant<int, 0>{}, std::false_type{}, std::false_type{});
+            }
+            if (t < kt1) tile(t, std::integral_constant<int, 1>{}, std::false_type{}, std::false_type{});
         }
         __builtin_amdgcn_sched_barrier(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -600,6 +600,7 @@ def train_bench(args, model, x, dev, rank, world, kwargs, rehearsal=False):
             "metric": f"fine-tune frames/sec ({SH}x{SW}, T={T} clip, LoRA factors trainable)", "value": round(frames_n / dt, 2), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "precision": PRECISION_NOTE["f32"] + " (the fine-tune step: forward, loss and backward)",
             "config": {"workload": f"ViT-{args.encoder[-1].upper()} endodav fine-tune step ({args.lora}{' + temporal_lora' if args.temporal_lora else ''} r=4, "
                                    f"{'conv head, conv_depth_* trainable' if args.conv_head else 'VDA head'}): forward + {loss_name} + HIP backward + gradient "
                                    f"all-reduce + AdamW, {args.clips} synthetic clip(s) of T={T} {x.shape[-2]}x{x.shape[-1]} frames -> image_shape {SH}x{SW} per GPU per step",
